@@ -1,0 +1,28 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def load_weights(fold=1):
+    z = np.load(os.path.join(GOLDEN, "weights_fold%d.npz" % fold))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def sd1():
+    return load_weights(1)
