@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ESPNet (p=2, q=8, 5 classes) patches/sec on 1024x512 BGR tiles.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path over one batch of 32 synthetic uint8 tiles already resident in
+HBM: normalise -> ESPNet forward -> argmax -> uint8 masks + per-class pixel counts
+(reference loop body: module/espnet/test/VisualizeResults_iou.py:107-128,151-155).  N > 1 runs one
+process per GPU (torch.distributed / RCCL): every rank owns its own tile range (weak scaling) and
+the only exchange is one all-reduce of the per-class pixel totals at the end of the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from glomeruli_segmentation_amd.engine import EspnetEngine  # noqa: E402
+from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile  # noqa: E402
+
+BATCH = 32
+H, W = 512, 1024
+FLOP_PER_TILE = 7.267e9          # conv/deconv MACs x 2, unpadded channel counts
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+DOMINANT = "conv_l3_esp_branches"
+
+
+def load_weights():
+    z = np.load(os.path.join(REPO, "tests", "golden", "weights_fold1.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def make_batch(rank):
+    # the first four tiles of rank 0 are the golden seeds 0..3 so that parity is checked in-line
+    return np.stack([synth_tile(rank * BATCH + i) for i in range(BATCH)])
+
+
+def host_cores():
+    """CPU threads this process may really use: the cgroup quota when there is one (a GPU box hands
+    each job a share of the host), else the affinity mask."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def cpu_baseline(sd, tiles, mean, std):
+    """The torch-operator port of the reference graph on this box's host cores; bounded sample."""
+    from oracle import espnet_torch_port as port   # bench's cpu_baseline leg only
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    bs = 4
+    x = port.preprocess(tiles[:bs], mean, std)
+    port.espnet_forward(x, tsd)                      # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        port.espnet_forward(x, tsd)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or reps >= 10:
+            break
+    return {"value": round(bs * reps / el, 3), "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": "%d x batch-%d forward of the 1024x512 workload through torch CPU ops (oracle/espnet_torch_port.py)"
+                      % (reps, bs)}
+
+
+def parity_vs_golden(mask_np):
+    from oracle import espnet_oracle as orc       # checker only
+    z = np.load(os.path.join(REPO, "tests", "golden", "masks_fold1.npz"))
+    conf = np.zeros((5, 5), dtype=np.int64)
+    for s in range(4):
+        conf += orc.confusion(mask_np[s], z["mask_%d" % s])
+    return {"miou_vs_reference": round(orc.present_class_miou(conf), 6),
+            "pixel_agreement": round(float(np.trace(conf)) / float(conf.sum()), 7), "tiles": 4}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    sd = load_weights()
+    mean, std = FOLD_MEAN_STD[1]
+    eng = EspnetEngine(sd, classes=5, p=2, q=8)
+    eng.reserve(BATCH, H, W)
+    tiles_np = make_batch(rank)
+    tiles = torch.from_numpy(tiles_np).to(dev)
+    mask = torch.empty((BATCH, H, W), dtype=torch.uint8, device=dev)
+    hist = torch.empty((BATCH, 5), dtype=torch.int64, device=dev)
+    totals = torch.zeros(5, dtype=torch.int64, device=dev)
+
+    def step():
+        eng.segment(tiles, mean, std, out_mask=mask, out_hist=hist)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    def timed(steps):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+            totals.add_(hist.sum(0))
+        if dist is not None:
+            dist.all_reduce(totals)        # the one exchange: slide-level per-class pixel totals
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        return time.perf_counter() - t0
+
+    elapsed = timed(args.steps)            # the reported number: no instrumentation in the stream
+    # same K steps again with a HIP event pair around every kernel on the launch stream: per-kernel
+    # durations for the roofline line (the event packets lengthen kernel boundaries, so this pass is
+    # not the one quoted as throughput; its wall time is reported beside it)
+    eng.profile(True)
+    elapsed_prof = timed(args.steps)
+    prof = eng.profile_read()
+    eng.profile(False)
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        n = max(world, 1)
+        total_tiles = n * BATCH * args.steps
+        value = total_tiles / elapsed
+        dom = next((k for k in prof if k["name"] == DOMINANT), None)
+        roof = None
+        kernels = {}
+        for k in prof:
+            kernels[k["name"]] = {"avg_ms": round(k["total_ms"] / max(k["launches"], 1), 4), "launches": k["launches"]}
+        if dom:
+            avg_s = dom["total_ms"] / dom["launches"] * 1e-3
+            achieved = dom["flops_per_tile"] * BATCH / avg_s / 1e12
+            roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_s * 1e3, 4),
+                    "launches_timed": dom["launches"], "instrumented_ms_per_step": round(elapsed_prof / args.steps * 1e3, 3),
+                    "whole_net_frac": round(value / n * FLOP_PER_TILE / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+        out = {
+            "metric": "patches/sec (1024x512 RGB) ESPNet p=2 q=8 5 classes", "value": round(value, 2),
+            "unit": "patches/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ESPNet p=2 q=8 encoder+decoder, batch=32 synthetic 1024x512 uint8 BGR tiles per GPU, "
+                                   "normalise+forward+argmax+counts, inputs resident in HBM",
+                       "global_batch": n * BATCH, "tile": [H, W], "weights": "espnet_fold1 (tests/golden)",
+                       "parallelism": "tile-range per rank x%d" % n},
+            "roofline": roof,
+            "kernels_avg_ms": kernels,
+            "parity": parity_vs_golden(mask[:4].cpu().numpy()),
+        }
+        if n == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, tiles_np, mean, std)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

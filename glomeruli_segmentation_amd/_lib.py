@@ -1,0 +1,87 @@
+"""ctypes binding of libglomseg.so (include/glomseg.h).  No fallback: if the HIP library is
+missing or fails to load this raises, so a GPU box can never pass on a silent CPU path."""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libglomseg.so")
+
+GS_OK = 0
+GS_IN_U8_BGR_NHWC = 0
+GS_IN_F32_NCHW = 1
+ABI_VERSION = 1
+
+STATUS_NAMES = {0: "GS_OK", 1: "GS_ERR_INVALID", 2: "GS_ERR_HIP", 3: "GS_ERR_NOMEM", 4: "GS_ERR_UNSUPPORTED",
+                5: "GS_ERR_NODEVICE"}
+
+
+class GlomsegError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), message))
+        self.status = status
+
+
+class LayerDesc(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 96), ("offset", ctypes.c_int64), ("ndim", ctypes.c_int32),
+                ("shape", ctypes.c_int32 * 4)]
+
+
+class KernelTime(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 64), ("total_ms", ctypes.c_double), ("launches", ctypes.c_int64),
+                ("flops_per_tile", ctypes.c_double)]
+
+
+_P = ctypes.c_void_p
+_FP = ctypes.POINTER(ctypes.c_float)
+_I = ctypes.c_int
+
+# every symbol include/glomseg.h declares: (restype, argtypes)
+PROTOTYPES = {
+    "gs_last_error": (ctypes.c_char_p, []),
+    "gs_abi_version": (_I, []),
+    "gs_espnet_create": (_I, [_P, ctypes.POINTER(LayerDesc), _I, _I, _I, _I, _I, ctypes.POINTER(_P)]),
+    "gs_espnet_destroy": (None, [_P]),
+    "gs_espnet_reserve": (_I, [_P, _I, _I, _I]),
+    "gs_espnet_forward": (_I, [_P, _P, _I, _I, _I, _I, _FP, _FP, _P, _P, _P, _P]),
+    "gs_espnet_segment_host": (_I, [_P, _P, _I, _I, _I, _FP, _FP, _I, _P, _P]),
+    "gs_espnet_ensemble_forward": (_I, [ctypes.POINTER(_P), _I, _P, _I, _I, _I, _FP, _FP, _P, _P, _P]),
+    "gs_espnet_read_stage": (_I, [_P, ctypes.c_char_p, _I, _P, ctypes.c_size_t, ctypes.POINTER(_I * 3)]),
+    "gs_espnet_profile_enable": (_I, [_P, _I]),
+    "gs_espnet_profile_read": (_I, [_P, ctypes.POINTER(KernelTime), _I, ctypes.POINTER(_I)]),
+    "gs_conv2d_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P]),
+    "gs_roialign": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
+    "gs_nms": (_I, [_P, _P, _I, ctypes.c_float, ctypes.c_float, _I, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library (once).  Import torch first in GPU processes so that libamdhip64.so.7 is
+    torch's copy: device pointers and streams are then shared with torch."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -m glomeruli_segmentation_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gs_abi_version() != ABI_VERSION:
+        raise ImportError("libglomseg.so ABI %d != binding ABI %d: rebuild" % (lib.gs_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != GS_OK:
+        raise GlomsegError(status, load().gs_last_error().decode("utf-8", "replace"))
+
+
+def fptr3(values):
+    arr = (ctypes.c_float * len(values))(*[float(v) for v in values])
+    return arr

@@ -1,0 +1,246 @@
+// Implicit-GEMM convolution on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32 /
+// v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate).
+//
+// One kernel template covers every dense contraction of the ESPNet trunk:
+//   * C / CDilated 1x1 and strided 3x3 "reduce" convolutions        (reference Model.py:98-104,135,178)
+//   * the five dilated 3x3 branches of DownSamplerB / the ESP block, their hierarchical
+//     feature fusion, channel concat, residual add, BatchNorm and PReLU (Model.py:144-160,187-214)
+//
+// Mapping.  GEMM-N (the MFMA column / the lane) is a run of MT consecutive output pixels of one
+// row, GEMM-M (the MFMA row) is the output channel, GEMM-K walks (tap, input channel).  A wave owns
+// P such pixel runs (P*MT consecutive pixels) and all output channels of them, so:
+//   * the B operand of a k-step is MT consecutive floats of an input row: one coalesced
+//     buffer_load_dword per pixel run straight from L1/L2 -- an fp32 MFMA needs only 4 B per lane
+//     per operand per 32-64 cycles, so no LDS staging of activations is needed; the zero halo of
+//     the activation buffers (gs::Act) makes every tap unconditional;
+//   * the A operand (weights, pre-packed [dilation][tap][cin][NROW] on the host) comes from LDS,
+//     one conflict-free ds_read_b32 per k-step shared by the P MFMAs of that step;
+//   * the fusion add2 = add1 + d4, add3 = add2 + d8, ... (Model.py:152-155) costs nothing: the
+//     d4/d8/d16 branches simply keep accumulating into the d2 accumulator, which is written out
+//     after each branch;
+//   * the lane<->pixel, register<->channel accumulator layout stores 128-byte (MT=32) or 64-byte
+//     (MT=16) row segments per channel plane.
+#pragma once
+#include "gs_internal.h"
+
+namespace gs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MT>
+struct Mfma;
+template <>
+struct Mfma<32> {
+    static constexpr int KL = 2, NACC = 16;
+    using acc_t = f32x16;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    // output row held by accumulator register r of a lane in k-group kq (= lane / 32)
+    static __device__ __forceinline__ int row(int r, int kq) { return (r & 3) + 8 * (r >> 2) + 4 * kq; }
+};
+template <>
+struct Mfma<16> {
+    static constexpr int KL = 4, NACC = 4;
+    using acc_t = f32x4;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int r, int kq) { return kq * 4 + r; }
+};
+
+struct ConvArgs {
+    // input activation (zero halo wide enough for every tap)
+    const float *in;
+    long long in_sn;
+    int in_sc, in_pitch, in_off;
+    unsigned in_img_bytes;
+    // packed weights (+ folded BN scale/shift/alpha appended), staged to LDS once per workgroup
+    const float *wpack;
+    int wfloats;
+    // output, optional residual
+    float *out;
+    long long out_sn;
+    int out_sc, out_pitch, out_off;
+    const float *res;
+    long long res_sn;
+    int res_sc, res_pitch, res_off;
+    int N, H, W;   // OUTPUT size
+    int strips;    // pixel strips per output row
+    int total_tasks;
+};
+
+template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int TXU,
+          int UNR, bool BNACT, bool RES>
+__global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
+{
+    using M = Mfma<MT>;
+    constexpr int KL = M::KL;
+    constexpr int NSTEP = CINP / KL;
+    constexpr int NROW = NOUT1 > NOUT ? NOUT1 : NOUT;
+    constexpr int COUT = NOUT1 + (NDIL - 1) * NOUT;
+    constexpr int TYN = TAPS == 9 ? 3 : 1;
+    constexpr int TXN = TAPS == 9 ? 3 : 1;
+    static_assert(CINP % KL == 0 && NSTEP % UNR == 0, "k-steps must tile");
+    static_assert(TAPS == 1 || TAPS == 9, "1x1 or 3x3");
+    static_assert(TXN % TXU == 0, "tap unroll");
+    static_assert(NROW <= MT, "one MFMA row block");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    for (int i = tid * 4; i < a.wfloats; i += WAVES * 64 * 4)
+        *reinterpret_cast<float4 *>(lds + i) = *reinterpret_cast<const float4 *>(a.wpack + i);
+    __syncthreads();
+    const float *bnp = lds + NDIL * TAPS * CINP * NROW;   // [scale | shift | alpha][COUT]
+
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane % MT, kq = lane / MT;
+    const int voff = (kq * a.in_sc + px * STRIDE) * 4;
+    const int lbase = kq * NROW + (px < NROW ? px : NROW - 1);
+
+    // Each wave takes a contiguous range of tasks; workgroups that share an XCD (equal
+    // blockIdx % 8 under round-robin dispatch: speed only) take neighbouring ranges, so one XCD's
+    // L2 sees a contiguous slab of images.
+    const int G = gridDim.x;
+    int vb = blockIdx.x;
+    if ((G & 7) == 0)
+        vb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const long long wg = (long long)vb * WAVES + wid;
+    const int t0 = (int)((long long)a.total_tasks * wg / ((long long)G * WAVES));
+    const int t1 = (int)((long long)a.total_tasks * (wg + 1) / ((long long)G * WAVES));
+    const int tasks_per_img = a.H * a.strips;
+
+    for (int task = t0; task < t1; ++task) {
+        const int n = task / tasks_per_img;
+        const int rem = task - n * tasks_per_img;
+        const int y = rem / a.strips;
+        const int x0 = (rem - y * a.strips) * (P * MT);
+
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(a.in + (long long)n * a.in_sn), 0, a.in_img_bytes, 0x00020000);
+        const int sbase = (a.in_off + y * STRIDE * a.in_pitch + x0 * STRIDE) * 4;
+
+        typename M::acc_t acc[P];
+
+        for (int di = 0; di < NDIL; ++di) {
+            const int d = 1 << di;
+            if (di < 2) {
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    acc[p] = (typename M::acc_t)(0.0f);
+            }
+            for (int ty = 0; ty < TYN; ++ty) {
+                for (int tx0 = 0; tx0 < TXN; tx0 += TXU) {
+                    for (int s0 = 0; s0 < NSTEP; s0 += UNR) {
+                        float aq[TXU][UNR];
+                        float bq[TXU][UNR][P];
+#pragma unroll
+                        for (int j = 0; j < TXU; ++j) {
+                            const int tap = TAPS == 9 ? ty * 3 + tx0 + j : 0;
+                            const int toff = TAPS == 9 ? ((ty - 1) * a.in_pitch + (tx0 + j - 1)) * d : 0;
+                            const int soff = sbase + toff * 4 + s0 * KL * a.in_sc * 4;
+                            const float *wl = lds + (di * TAPS + tap) * (CINP * NROW) + s0 * KL * NROW + lbase;
+#pragma unroll
+                            for (int u = 0; u < UNR; ++u) {
+                                aq[j][u] = wl[u * KL * NROW];
+#pragma unroll
+                                for (int p = 0; p < P; ++p)
+                                    bq[j][u][p] = __builtin_bit_cast(
+                                        float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                   rsrc, voff + p * MT * STRIDE * 4, soff + u * KL * a.in_sc * 4, 0));
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < TXU; ++j)
+#pragma unroll
+                            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                                for (int p = 0; p < P; ++p)
+                                    acc[p] = M::run(aq[j][u], bq[j][u][p], acc[p]);
+                    }
+                }
+            }
+
+            // write this branch's concat slot (the accumulator keeps running for the fusion adds)
+            const int nout = di == 0 ? NOUT1 : NOUT;
+            const int cb = di == 0 ? 0 : NOUT1 + (di - 1) * NOUT;
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r) {
+                const int ch = M::row(r, kq);
+                if (ch < nout) {
+                    const int c = cb + ch;
+                    float *orow = a.out + (long long)n * a.out_sn + (long long)c * a.out_sc + a.out_off +
+                                  y * a.out_pitch + x0 + px;
+                    const float *rrow = nullptr;
+                    if (RES)
+                        rrow = a.res + (long long)n * a.res_sn + (long long)c * a.res_sc + a.res_off +
+                               y * a.res_pitch + x0 + px;
+                    float scale = 1.0f, shift = 0.0f, alpha = 1.0f;
+                    if (BNACT) {
+                        scale = bnp[c];
+                        shift = bnp[COUT + c];
+                        alpha = bnp[2 * COUT + c];
+                    }
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        if (x0 + p * MT + px < a.W) {
+                            float v = acc[p][r];
+                            if (RES)
+                                v += rrow[p * MT];
+                            if (BNACT) {
+                                v = v * scale + shift;
+                                v = v > 0.0f ? v : alpha * v;
+                            }
+                            orow[p * MT] = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// number of floats of the LDS image for a configuration (weights, then 3*COUT BN/PReLU params)
+constexpr int conv_wfloats(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT, bool bn)
+{
+    const int nrow = NOUT1 > NOUT ? NOUT1 : NOUT;
+    const int cout = NOUT1 + (NDIL - 1) * NOUT;
+    const int n = NDIL * TAPS * CINP * nrow + (bn ? 3 * cout : 0);
+    return (n + 3) / 4 * 4;
+}
+
+template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int TXU,
+          int UNR, bool BNACT, bool RES>
+gs_status launch_conv_mfma(ConvArgs a, int num_cus, hipStream_t stream)
+{
+    auto kern = conv_mfma_kernel<MT, WAVES, CINP, TAPS, STRIDE, NDIL, NOUT1, NOUT, P, TXU, UNR, BNACT, RES>;
+    a.strips = cdiv(a.W, P * MT);
+    a.total_tasks = a.N * a.H * a.strips;
+    a.wfloats = conv_wfloats(CINP, TAPS, NDIL, NOUT1, NOUT, BNACT);
+    const size_t lds_bytes = (size_t)a.wfloats * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds_bytes));
+        attr_done = true;
+    }
+    // workgroups resident per CU by LDS, capped so a wave gets at least one task
+    int per_cu = (int)((160 * 1024) / (lds_bytes + 256));
+    if (per_cu < 1) per_cu = 1;
+    const int wave_slots = 8 / WAVES > 0 ? 8 / WAVES : 1;   // stay at <= 2 waves per SIMD
+    if (per_cu > wave_slots) per_cu = wave_slots;
+    int grid = num_cus * per_cu;
+    const int need = cdiv(a.total_tasks, WAVES);
+    if (grid > need) grid = need;
+    if (grid >= 8) grid = grid / 8 * 8;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, a);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+}  // namespace gs

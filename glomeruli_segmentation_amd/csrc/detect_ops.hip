@@ -1,0 +1,274 @@
+// Detector-side device primitives: NHWC convolution on the fp32 matrix cores, crop_and_resize
+// (the ROI pooling of TF object-detection Faster R-CNN graphs) and greedy IoU NMS.
+//
+// The reference's detector is an external TensorFlow-1.12 frozen graph fed through
+// sess.run (module/faster-rcnn/detect_glomus_test.py:350-352); neither its architecture nor its
+// weights are in the reference, so these kernels implement the published semantics of the TF ops
+// such graphs contain and are tested for self-consistency only (parity unpinned).
+#include <algorithm>
+#include <vector>
+
+#include "gs_internal.h"
+
+namespace gs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// conv2d NHWC: GEMM-M = output pixels (32 per wave), GEMM-N = output channels (32 per wave, on the
+// lanes, so NHWC stores are 128-byte rows), GEMM-K = (ky,kx,cin) two at a time.
+struct ConvNhwcArgs {
+    const float *in, *w, *bias;
+    float *out;
+    int n, h, w_, cin, kh, kw, cout, stride, pad, relu, ho, wo;
+};
+
+__global__ void __launch_bounds__(256) conv2d_nhwc_kernel(const ConvNhwcArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int r = lane & 31, kq = lane >> 5;
+    const long long npix = (long long)a.n * a.ho * a.wo;
+    const long long pix0 = ((long long)blockIdx.x * 4 + wid) * 32;
+    const int co0 = blockIdx.y * 32;
+    if (pix0 >= npix)
+        return;
+    // A row r = pixel pix0 + r
+    const long long pix = pix0 + r;
+    const bool pv = pix < npix;
+    const int ox = (int)(pix % a.wo), oy = (int)((pix / a.wo) % a.ho), img = (int)(pix / ((long long)a.wo * a.ho));
+    const int co = co0 + r;   // B column r = output channel
+    f32x16 acc = (f32x16)(0.0f);
+    for (int ky = 0; ky < a.kh; ++ky) {
+        const int iy = oy * a.stride - a.pad + ky;
+        for (int kx = 0; kx < a.kw; ++kx) {
+            const int ix = ox * a.stride - a.pad + kx;
+            const bool ok = pv && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w_;
+            const float *ip = a.in + (((long long)img * a.h + iy) * a.w_ + ix) * a.cin;
+            const float *wp = a.w + ((long long)(ky * a.kw + kx) * a.cin) * a.cout + co;
+            for (int c = 0; c < a.cin; c += 2) {
+                const int ci = c + kq;
+                const float av = (ok && ci < a.cin) ? ip[ci] : 0.0f;
+                const float bv = (co < a.cout && ci < a.cin) ? wp[(long long)ci * a.cout] : 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+        }
+    }
+    // D: column = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * kq (pixel)
+    if (co < a.cout) {
+        const float b = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const long long p = pix0 + (reg & 3) + 8 * (reg >> 2) + 4 * kq;
+            if (p < npix) {
+                float v = acc[reg] + b;
+                if (a.relu)
+                    v = fmaxf(v, 0.0f);
+                a.out[p * a.cout + co] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tf.image.crop_and_resize, method="bilinear", extrapolation_value=0.  One thread per
+// (box, y, x, channel); channels are innermost so loads/stores coalesce in NHWC.
+__global__ void __launch_bounds__(256)
+roialign_kernel(const float *feat, int n, int h, int w, int c, const float *boxes, const int *box_image, int n_boxes,
+                int crop, float *out)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)n_boxes * crop * crop * c;
+    if (idx >= total)
+        return;
+    const int ch = (int)(idx % c);
+    const int x = (int)((idx / c) % crop);
+    const int y = (int)((idx / ((long long)c * crop)) % crop);
+    const int b = (int)(idx / ((long long)c * crop * crop));
+    const float y1 = boxes[b * 4 + 0], x1 = boxes[b * 4 + 1], y2 = boxes[b * 4 + 2], x2 = boxes[b * 4 + 3];
+    const int img = box_image[b];
+    float v = 0.0f;
+    if (img >= 0 && img < n) {
+        const float hs = crop > 1 ? (y2 - y1) * (float)(h - 1) / (float)(crop - 1) : 0.0f;
+        const float ws = crop > 1 ? (x2 - x1) * (float)(w - 1) / (float)(crop - 1) : 0.0f;
+        const float in_y = crop > 1 ? y1 * (float)(h - 1) + (float)y * hs : 0.5f * (y1 + y2) * (float)(h - 1);
+        const float in_x = crop > 1 ? x1 * (float)(w - 1) + (float)x * ws : 0.5f * (x1 + x2) * (float)(w - 1);
+        if (in_y >= 0.0f && in_y <= (float)(h - 1) && in_x >= 0.0f && in_x <= (float)(w - 1)) {
+            const int ty = (int)floorf(in_y), by = (int)ceilf(in_y);
+            const int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
+            const float fy = in_y - (float)ty, fx = in_x - (float)lx;
+            const float *base = feat + (long long)img * h * w * c + ch;
+            const float tl = base[((long long)ty * w + lx) * c], tr = base[((long long)ty * w + rx) * c];
+            const float bl = base[((long long)by * w + lx) * c], br = base[((long long)by * w + rx) * c];
+            const float top = tl + (tr - tl) * fx, bot = bl + (br - bl) * fx;
+            v = top + (bot - top) * fy;
+        }
+    }
+    out[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NMS.  (1) rank boxes by descending score (ties: lower index first) with an O(k^2) count, which
+// also yields the sorted order without a sort network; (2) 64-bit suppression masks with one wave
+// ballot per 64x64 block; (3) one wave walks the sorted list.
+__device__ __forceinline__ float box_iou(const float *a, const float *b)
+{
+    const float ay1 = fminf(a[0], a[2]), ax1 = fminf(a[1], a[3]), ay2 = fmaxf(a[0], a[2]), ax2 = fmaxf(a[1], a[3]);
+    const float by1 = fminf(b[0], b[2]), bx1 = fminf(b[1], b[3]), by2 = fmaxf(b[0], b[2]), bx2 = fmaxf(b[1], b[3]);
+    const float aa = (ay2 - ay1) * (ax2 - ax1), ab = (by2 - by1) * (bx2 - bx1);
+    if (aa <= 0.0f || ab <= 0.0f)
+        return 0.0f;
+    const float ih = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.0f);
+    const float iw = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.0f);
+    const float inter = ih * iw;
+    return inter / (aa + ab - inter);
+}
+
+__global__ void __launch_bounds__(256) nms_rank_kernel(const float *scores, int k, float score_thr, int *order, int *n_valid)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= k)
+        return;
+    const float s = scores[i];
+    if (!(s > score_thr))
+        return;
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+        const float t = scores[j];
+        rank += (t > score_thr) && (t > s || (t == s && j < i));
+    }
+    order[rank] = i;
+    atomicAdd(n_valid, 1);
+}
+
+__global__ void __launch_bounds__(64)
+nms_mask_kernel(const float *boxes, const int *order, const int *n_valid, float thr, int words, unsigned long long *mask)
+{
+    const int nv = *n_valid;
+    const int row = blockIdx.y * 64 + threadIdx.x;   // sorted position of the candidate suppressor
+    const int colb = blockIdx.x;                     // 64-wide block of sorted positions it may suppress
+    if (blockIdx.y * 64 >= nv || colb * 64 >= nv)
+        return;
+    __shared__ float cb[64][4];
+    const int cpos = colb * 64 + threadIdx.x;
+    if (cpos < nv) {
+        const float *p = boxes + (long long)order[cpos] * 4;
+        cb[threadIdx.x][0] = p[0];
+        cb[threadIdx.x][1] = p[1];
+        cb[threadIdx.x][2] = p[2];
+        cb[threadIdx.x][3] = p[3];
+    }
+    __syncthreads();
+    if (row >= nv)
+        return;
+    float rb[4];
+    const float *p = boxes + (long long)order[row] * 4;
+    rb[0] = p[0];
+    rb[1] = p[1];
+    rb[2] = p[2];
+    rb[3] = p[3];
+    unsigned long long bits = 0;
+    for (int j = 0; j < 64; ++j) {
+        const int c = colb * 64 + j;
+        if (c < nv && c > row && box_iou(rb, cb[j]) > thr)
+            bits |= 1ull << j;
+    }
+    mask[(long long)row * words + colb] = bits;
+}
+
+__global__ void __launch_bounds__(64)
+nms_scan_kernel(const unsigned long long *mask, const int *order, const int *n_valid, int words, int max_out, int *keep,
+                int *n_keep)
+{
+    extern __shared__ unsigned long long removed[];   // [words]
+    const int nv = *n_valid;
+    for (int w = threadIdx.x; w < words; w += 64)
+        removed[w] = 0;
+    __syncthreads();
+    int kept = 0;
+    for (int i = 0; i < nv && kept < max_out; ++i) {
+        const bool dead = (removed[i >> 6] >> (i & 63)) & 1ull;   // wave-uniform
+        if (!dead) {
+            if (threadIdx.x == 0)
+                keep[kept] = order[i];
+            ++kept;
+            for (int w = (i >> 6) + threadIdx.x; w < words; w += 64)
+                removed[w] |= mask[(long long)i * words + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        *n_keep = kept;
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" {
+
+gs_status gs_conv2d_nhwc(const float *in, int n, int h, int w, int cin, const float *weight, int kh, int kw, int cout,
+                         const float *bias_or_null, int stride, int pad, int relu, float *out, void *hip_stream)
+{
+    GS_REQUIRE(in && weight && out, "gs_conv2d_nhwc: null pointer");
+    GS_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
+               "gs_conv2d_nhwc: bad dimensions");
+    ConvNhwcArgs a{in, weight, bias_or_null, out, n, h, w, cin, kh, kw, cout, stride, pad, relu, 0, 0};
+    a.ho = (h + 2 * pad - kh) / stride + 1;
+    a.wo = (w + 2 * pad - kw) / stride + 1;
+    GS_REQUIRE(a.ho > 0 && a.wo > 0, "gs_conv2d_nhwc: empty output");
+    const long long npix = (long long)n * a.ho * a.wo;
+    dim3 grid((unsigned)((npix + 127) / 128), (unsigned)((cout + 31) / 32));
+    hipLaunchKernelGGL(conv2d_nhwc_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+gs_status gs_roialign(const float *feat, int n, int h, int w, int c, const float *boxes, const int *box_image, int n_boxes,
+                      int crop, float *out, void *hip_stream)
+{
+    GS_REQUIRE(feat && boxes && box_image && out, "gs_roialign: null pointer");
+    GS_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && crop > 0 && n_boxes >= 0, "gs_roialign: bad dimensions");
+    if (n_boxes == 0)
+        return GS_OK;
+    const long long total = (long long)n_boxes * crop * crop * c;
+    hipLaunchKernelGGL(roialign_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(hip_stream), feat, n, h, w, c, boxes, box_image, n_boxes, crop, out);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+gs_status gs_nms(const float *boxes, const float *scores, int k, float iou_threshold, float score_threshold, int max_out,
+                 int *keep, int *n_keep, void *hip_stream)
+{
+    GS_REQUIRE(boxes && scores && keep && n_keep, "gs_nms: null pointer");
+    GS_REQUIRE(k >= 0 && max_out >= 0, "gs_nms: negative count");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (k == 0 || max_out == 0) {
+        GS_HIP(hipMemsetAsync(n_keep, 0, sizeof(int), s));
+        return GS_OK;
+    }
+    const int words = (k + 63) / 64;
+    GS_REQUIRE((size_t)words * 8 <= 64 * 1024, "gs_nms: more than %d boxes are not supported", 8192 * 64);
+    // scratch: order[k] | n_valid | mask[k*words]
+    const size_t scratch = round_up((size_t)(k + 4) * sizeof(int), 16) + (size_t)k * words * 8;
+    char *d = nullptr;
+    GS_HIP(hipMalloc(reinterpret_cast<void **>(&d), scratch));
+    int *order = reinterpret_cast<int *>(d);
+    int *n_valid = order + k;
+    unsigned long long *mask = reinterpret_cast<unsigned long long *>(d + round_up((size_t)(k + 4) * sizeof(int), 16));
+    hipError_t e = hipMemsetAsync(d, 0, scratch, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(nms_rank_kernel, dim3((k + 255) / 256), dim3(256), 0, s, scores, k, score_threshold, order, n_valid);
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words), dim3(64), 0, s, boxes, order, n_valid, iou_threshold, words, mask);
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)words * 8, s, mask, order, n_valid, words, max_out, keep, n_keep);
+        e = hipGetLastError();
+    }
+    hipError_t e2 = hipStreamSynchronize(s);   // scratch is freed below
+    hipFree(d);
+    GS_HIP(e);
+    GS_HIP(e2);
+    return GS_OK;
+}
+
+}  // extern "C"

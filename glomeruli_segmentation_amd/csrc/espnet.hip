@@ -1,0 +1,823 @@
+// gs_espnet_*: model handle, weight packing, HBM workspace and the forward schedule.
+// Reference path replaced: module/espnet/test/Model.py ESPNet.forward (:341-378) /
+// ESPNet_Encoder.forward (:273-304) called from module/espnet/test/VisualizeResults_iou.py:123.
+#include <cmath>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "conv_mfma.h"
+#include "espnet_kernels.h"
+
+namespace gs {
+
+static thread_local std::string g_err;
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel configurations (template arguments of conv_mfma_kernel); see DESIGN.md "kernels"
+//                       MT WAVES CINP TAPS STRIDE NDIL NOUT1 NOUT  P TXU UNR
+#define CFG_L2_C1S       16, 8,   20,  9,   2,     1,   12,   12,   8, 1,  5
+#define CFG_L2_C1        16, 8,   64,  1,   1,     1,   12,   12,   8, 1,  8
+#define CFG_L2_BR        16, 8,   12,  9,   1,     5,   16,   12,   8, 3,  3
+#define CFG_L3_C1S       32, 8,   132, 9,   2,     1,   25,   25,   4, 1,  11
+#define CFG_L3_C1        32, 8,   128, 1,   1,     1,   25,   25,   4, 1,  16
+#define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 1,  13
+
+enum KernelId {
+    K_STEM, K_POOL, K_L2_C1S, K_L2_DOWN, K_L2_C1, K_L2_ESP, K_CAT_B2, K_L3_C1S, K_L3_DOWN, K_L3_C1, K_L3_ESP,
+    K_DEC1, K_DEC2, K_DEC3, K_DEC4, K_COUNT
+};
+static const char *kKernelNames[K_COUNT] = {
+    "stem_kernel", "pool_kernel", "conv_l2_reduce_s2", "conv_l2_down_branches", "conv_l2_reduce_1x1",
+    "conv_l2_esp_branches", "cat_b2_kernel", "conv_l3_reduce_s2", "conv_l3_down_branches", "conv_l3_reduce_1x1",
+    "conv_l3_esp_branches", "dec1_kernel", "dec2_kernel", "dec3_kernel", "dec4_kernel"};
+
+struct PackedConv {   // float offsets into the device weight blob
+    long long c1 = -1, br = -1;
+};
+
+struct Model {
+    int classes = 0, p = 0, q = 0;
+    bool encoder_only = false;
+    int device = 0, num_cus = 256;
+    float *dblob = nullptr;
+    // offsets (floats) into dblob
+    long long w1, bn1, b1, b2, b3, wcls, br, wup3, w3c, cbr0, wcc, bncc, wup2, bnu2, wconv, bnconv, wclassifier;
+    PackedConv l2_0;
+    std::vector<PackedConv> l2, l3;
+    PackedConv l3_0;
+
+    // workspace
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    int ws_n = 0, ws_h = 0, ws_w = 0;
+    Act a0, inp1, inp2, r2, bb[3], a1, r3, cc[3], o2c, tt, ee;
+    float *prob = nullptr;   // ensemble scratch
+    size_t prob_bytes = 0;
+    std::map<std::string, std::pair<Act, int>> stages;   // name -> (activation, channels) of the last forward
+    int last_n = 0;
+
+    // profiling
+    bool profile = false;
+    struct Ev { hipEvent_t a, b; int k; };
+    std::vector<Ev> events;
+    double prof_ms[K_COUNT] = {0};
+    long long prof_launches[K_COUNT] = {0};
+    double prof_flops[K_COUNT] = {0};
+};
+
+// ------------------------------------------------------------------------------------------
+struct WeightTable {
+    const float *blob;
+    std::map<std::string, const gs_layer_desc *> by_name;
+    std::string prefix;   // "encoder." for the full net, "" for ESPNet_Encoder tables
+    bool ok = true;
+    const float *get(const std::string &name, std::initializer_list<int> shape)
+    {
+        auto it = by_name.find(name);
+        if (it == by_name.end()) {
+            set_error("weight tensor '%s' missing from the table", name.c_str());
+            ok = false;
+            return nullptr;
+        }
+        const gs_layer_desc *d = it->second;
+        int i = 0;
+        bool match = d->ndim == (int)shape.size();
+        for (int s : shape)
+            match = match && d->shape[i++] == s;
+        if (!match) {
+            set_error("weight tensor '%s' has the wrong shape", name.c_str());
+            ok = false;
+            return nullptr;
+        }
+        return blob + d->offset;
+    }
+};
+
+struct BlobBuilder {
+    std::vector<float> data;
+    long long reserve(size_t n)
+    {
+        const size_t at = (data.size() + 3) / 4 * 4;   // 16-byte aligned pieces (float4 LDS staging)
+        data.resize(at + (n + 3) / 4 * 4, 0.0f);
+        return (long long)at;
+    }
+    long long push(const float *src, size_t n)
+    {
+        const long long at = reserve(n);
+        std::memcpy(data.data() + at, src, n * sizeof(float));
+        return at;
+    }
+};
+
+// BatchNorm2d(eps=1e-3).eval() folded to y = x*scale + shift, plus the PReLU slope (1 when absent):
+// layout [scale | shift | alpha][C].  reference: Model.py:21-22,44-45,141-142
+static bool fold_bn(WeightTable &t, const std::string &bn, const std::string &act, int C, float *dst, bool with_alpha = true)
+{
+    const float *g = t.get(bn + ".weight", {C}), *b = t.get(bn + ".bias", {C});
+    const float *m = t.get(bn + ".running_mean", {C}), *v = t.get(bn + ".running_var", {C});
+    const float *al = act.empty() ? nullptr : t.get(act + ".weight", {C});
+    if (!t.ok)
+        return false;
+    for (int c = 0; c < C; ++c) {
+        const double inv = 1.0 / std::sqrt((double)v[c] + 1e-3);
+        dst[c] = (float)((double)g[c] * inv);
+        dst[C + c] = (float)((double)b[c] - (double)m[c] * (double)g[c] * inv);
+        if (with_alpha)
+            dst[2 * C + c] = al ? al[c] : 1.0f;
+    }
+    return true;
+}
+
+// conv weight [cout][cin][k][k] -> LDS image rows [tap][cin_padded][nrow] of dilation slot `slot`
+static void pack_conv(const float *w, int cout, int cin, int k, float *dst, int slot, int taps, int cinp, int nrow)
+{
+    for (int tap = 0; tap < taps; ++tap)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co)
+                dst[(((size_t)slot * taps + tap) * cinp + ci) * nrow + co] = w[((size_t)co * cin + ci) * k * k + tap];
+}
+
+static bool pack_block(WeightTable &t, BlobBuilder &bb, const std::string &pre, bool down, int level, PackedConv &pc)
+{
+    // level 2: cin 19 (down) / 64, n = 12, n1 = 16;  level 3: cin 131 (down) / 128, n = 25, n1 = 28
+    const int n = level == 2 ? 12 : 25, n1 = level == 2 ? 16 : 28, nOut = n1 + 4 * n;
+    const int cin = level == 2 ? (down ? 19 : 64) : (down ? 131 : 128);
+    const int kl = level == 2 ? 4 : 2;
+    const int cinp = (cin + kl - 1) / kl * kl;
+    const int taps = down ? 9 : 1;
+    const float *wc1 = t.get(pre + ".c1.conv.weight", {n, cin, down ? 3 : 1, down ? 3 : 1});
+    if (!t.ok)
+        return false;
+    pc.c1 = bb.reserve(conv_wfloats(cinp, taps, 1, n, n, false));
+    pack_conv(wc1, n, cin, down ? 3 : 1, bb.data.data() + pc.c1, 0, taps, cinp, n);
+
+    const int rcinp = (n + kl - 1) / kl * kl;
+    pc.br = bb.reserve(conv_wfloats(rcinp, 9, 5, n1, n, true));
+    static const char *dn[5] = {".d1", ".d2", ".d4", ".d8", ".d16"};
+    for (int di = 0; di < 5; ++di) {
+        const int co = di == 0 ? n1 : n;
+        const float *w = t.get(pre + dn[di] + ".conv.weight", {co, n, 3, 3});
+        if (!t.ok)
+            return false;
+        pack_conv(w, co, n, 3, bb.data.data() + pc.br, di, 9, rcinp, n1);
+    }
+    float *bnp = bb.data.data() + pc.br + (size_t)5 * 9 * rcinp * n1;
+    // DownSamplerB: self.bn / self.act (Model.py:141-142); ESP block: self.bn = BR(nOut) (Model.py:184)
+    return down ? fold_bn(t, pre + ".bn", pre + ".act", nOut, bnp) : fold_bn(t, pre + ".bn.bn", pre + ".bn.act", nOut, bnp);
+}
+
+// ------------------------------------------------------------------------------------------
+static Act make_act(int C, int Cp, int H, int W, int pad_t, int pad_b, int pad_l, int pad_r)
+{
+    Act a;
+    a.C = C;
+    a.Cp = Cp;
+    a.H = H;
+    a.W = W;
+    a.pitch = (int)round_up(pad_l + W + pad_r, 4);
+    a.sc = (pad_t + H + pad_b) * a.pitch;
+    a.off = pad_t * a.pitch + pad_l;
+    a.sn = (long long)Cp * a.sc;
+    return a;
+}
+
+static gs_status layout_workspace(Model *m, int n, int H, int W)
+{
+    if (m->ws && n <= m->ws_n && H == m->ws_h && W == m->ws_w)
+        return GS_OK;
+    if (m->ws) {
+        GS_HIP(hipDeviceSynchronize());
+        GS_HIP(hipFree(m->ws));
+        m->ws = nullptr;
+    }
+    const int cls = m->classes;
+    const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8;
+    m->a0 = make_act(19, 20, H1, W1, 1, 0, 4, 4);     // read by the stride-2 3x3 (needs top/left zero pad)
+    m->inp1 = make_act(3, 3, H1, W1, 0, 0, 0, 0);
+    m->inp2 = make_act(3, 3, H2, W2, 0, 0, 0, 0);
+    m->r2 = make_act(12, 12, H2, W2, 16, 16, 16, 16);  // dilation up to 16
+    for (int i = 0; i < 3; ++i)
+        m->bb[i] = make_act(64, 64, H2, W2, 0, 0, 0, 0);
+    m->a1 = make_act(131, 132, H2, W2, 1, 0, 4, 4);
+    m->r3 = make_act(25, 26, H3, W3, 16, 16, 16, 16);
+    for (int i = 0; i < 3; ++i)
+        m->cc[i] = make_act(128, 128, H3, W3, 0, 0, 0, 0);
+    m->o2c = make_act(cls, cls, H2, W2, 0, 0, 0, 0);
+    m->tt = make_act(2 * cls, 2 * cls, H2, W2, 0, 0, 0, 0);
+    m->ee = make_act(cls, cls, H1, W1, 0, 0, 0, 0);
+    Act *all[] = {&m->a0, &m->inp1, &m->inp2, &m->r2, &m->bb[0], &m->bb[1], &m->bb[2], &m->a1, &m->r3,
+                  &m->cc[0], &m->cc[1], &m->cc[2], &m->o2c, &m->tt, &m->ee};
+    const size_t slack = 64 * 1024;   // strips may over-read past a buffer's last row (masked lanes only)
+    size_t total = 0;
+    for (Act *a : all)
+        total += round_up(a->bytes(n) + slack, 256);
+    void *ws = nullptr;
+    if (hipMalloc(&ws, total) != hipSuccess) {
+        set_error("workspace allocation of %zu bytes failed (n=%d, %dx%d)", total, n, H, W);
+        return GS_ERR_NOMEM;
+    }
+    GS_HIP(hipMemset(ws, 0, total));   // halos and padded channel planes are zero from here on
+    size_t at = 0;
+    for (Act *a : all) {
+        a->base = reinterpret_cast<float *>(static_cast<char *>(ws) + at);
+        at += round_up(a->bytes(n) + slack, 256);
+    }
+    m->ws = ws;
+    m->ws_bytes = total;
+    m->ws_n = n;
+    m->ws_h = H;
+    m->ws_w = W;
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+struct Launcher {
+    Model *m;
+    hipStream_t s;
+    gs_status st = GS_OK;
+    int n;
+    template <typename F>
+    void run(int kid, double flops_per_tile, F &&f)
+    {
+        if (st != GS_OK)
+            return;
+        Model::Ev ev{nullptr, nullptr, kid};
+        if (m->profile) {
+            if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess ||
+                hipEventRecord(ev.a, s) != hipSuccess) {
+                set_error("profiling event setup failed");
+                st = GS_ERR_HIP;
+                return;
+            }
+        }
+        st = f();
+        if (st == GS_OK && hipGetLastError() != hipSuccess) {
+            set_error("launch of %s failed", kKernelNames[kid]);
+            st = GS_ERR_HIP;
+        }
+        if (m->profile && st == GS_OK) {
+            hipEventRecord(ev.b, s);
+            m->events.push_back(ev);
+            m->prof_flops[kid] = flops_per_tile;
+        }
+    }
+};
+
+static ConvArgs conv_args(const Act &in, const float *wpack, const Act &out, const Act *res, int n)
+{
+    ConvArgs a{};
+    a.in = in.base;
+    a.in_sn = in.sn;
+    a.in_sc = in.sc;
+    a.in_pitch = in.pitch;
+    a.in_off = in.off;
+    a.in_img_bytes = (unsigned)(in.sn * sizeof(float));
+    a.wpack = wpack;
+    a.out = out.base;
+    a.out_sn = out.sn;
+    a.out_sc = out.sc;
+    a.out_pitch = out.pitch;
+    a.out_off = out.off;
+    if (res) {
+        a.res = res->base;
+        a.res_sn = res->sn;
+        a.res_sc = res->sc;
+        a.res_pitch = res->pitch;
+        a.res_off = res->off;
+    }
+    a.N = n;
+    a.H = out.H;
+    a.W = out.W;
+    return a;
+}
+
+static inline unsigned blocks_for(long long items) { return (unsigned)((items + 255) / 256); }
+
+template <int CLS>
+static gs_status forward_impl(Model *m, const void *in, int in_format, int n, int H, int W, const float *mean,
+                              const float *stdv, float *logits, uint8_t *mask, unsigned long long *hist, hipStream_t s)
+{
+    const float *wb = m->dblob;
+    Launcher L{m, s, GS_OK, n};
+    const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8;
+    const double px1 = (double)H1 * W1, px2 = (double)H2 * W2, px3 = (double)H3 * W3;
+    m->stages.clear();
+    m->last_n = n;
+    // a ping-pong buffer that is written again no longer holds the stage recorded for it earlier
+    auto set_stage = [&](const std::string &name, const Act &act, int C) {
+        for (auto it = m->stages.begin(); it != m->stages.end();)
+            it = it->second.first.base == act.base ? m->stages.erase(it) : std::next(it);
+        m->stages[name] = {act, C};
+    };
+
+    // ---- stem (Model.py:346-350)
+    L.run(K_STEM, px1 * (27 * 16 * 2), [&] {
+        StemArgs a{};
+        a.in = in;
+        for (int i = 0; i < 3; ++i) {
+            a.mean[i] = mean ? mean[i] : 0.0f;
+            a.std[i] = stdv ? stdv[i] : 1.0f;
+        }
+        a.w1 = wb + m->w1;
+        a.bn1 = wb + m->bn1;
+        a.b1 = wb + m->b1;
+        a.a0 = view(m->a0);
+        a.inp1 = view(m->inp1);
+        a.N = n;
+        a.H = H;
+        a.W = W;
+        if (in_format == GS_IN_U8_BGR_NHWC)
+            hipLaunchKernelGGL(stem_kernel<true>, dim3(blocks_for((long long)n * H1 * W1)), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(stem_kernel<false>, dim3(blocks_for((long long)n * H1 * W1)), dim3(256), 0, s, a);
+        return GS_OK;
+    });
+    L.run(K_POOL, 0, [&] {
+        hipLaunchKernelGGL(pool_kernel, dim3(blocks_for((long long)n * 3 * H2 * W2)), dim3(256), 0, s, view(m->inp1),
+                           view(m->inp2), n, 3);
+        return GS_OK;
+    });
+    set_stage("b1", m->a0, 19);
+    set_stage("sample2", m->inp2, 3);
+
+    // ---- level 2 (Model.py:351-357): DownSamplerB(19,64) then p ESP blocks
+    L.run(K_L2_C1S, px2 * (19 * 9 * 12 * 2), [&] {
+        return launch_conv_mfma<CFG_L2_C1S, false, false>(conv_args(m->a0, wb + m->l2_0.c1, m->r2, nullptr, n), m->num_cus, s);
+    });
+    L.run(K_L2_DOWN, px2 * (12 * 9 * 64 * 2), [&] {
+        return launch_conv_mfma<CFG_L2_BR, true, false>(conv_args(m->r2, wb + m->l2_0.br, m->bb[0], nullptr, n), m->num_cus, s);
+    });
+    set_stage("level2_0", m->bb[0], 64);
+    int cur2 = 0;
+    for (int i = 0; i < m->p; ++i) {
+        const int nxt = cur2 == 1 ? 2 : 1;
+        L.run(K_L2_C1, px2 * (64 * 12 * 2), [&] {
+            return launch_conv_mfma<CFG_L2_C1, false, false>(conv_args(m->bb[cur2], wb + m->l2[i].c1, m->r2, nullptr, n), m->num_cus, s);
+        });
+        L.run(K_L2_ESP, px2 * (12 * 9 * 64 * 2), [&] {
+            return launch_conv_mfma<CFG_L2_BR, true, true>(conv_args(m->r2, wb + m->l2[i].br, m->bb[nxt], &m->bb[cur2], n), m->num_cus, s);
+        });
+        cur2 = nxt;
+        set_stage("level2." + std::to_string(i), m->bb[cur2], 64);
+    }
+    // ---- b2 (Model.py:359)
+    L.run(K_CAT_B2, 0, [&] {
+        hipLaunchKernelGGL(cat_b2_kernel, dim3(blocks_for((long long)n * 131 * H2 * W2)), dim3(256), 0, s, view(m->bb[cur2]),
+                           view(m->bb[0]), view(m->inp2), wb + m->b2, view(m->a1), n);
+        return GS_OK;
+    });
+    set_stage("b2", m->a1, 131);
+
+    // ---- level 3 (Model.py:361-366)
+    L.run(K_L3_C1S, px3 * (131 * 9 * 25 * 2), [&] {
+        return launch_conv_mfma<CFG_L3_C1S, false, false>(conv_args(m->a1, wb + m->l3_0.c1, m->r3, nullptr, n), m->num_cus, s);
+    });
+    L.run(K_L3_DOWN, px3 * (25 * 9 * 128 * 2), [&] {
+        return launch_conv_mfma<CFG_L3_BR, true, false>(conv_args(m->r3, wb + m->l3_0.br, m->cc[0], nullptr, n), m->num_cus, s);
+    });
+    set_stage("level3_0", m->cc[0], 128);
+    int cur3 = 0;
+    for (int i = 0; i < m->q; ++i) {
+        const int nxt = cur3 == 1 ? 2 : 1;
+        L.run(K_L3_C1, px3 * (128 * 25 * 2), [&] {
+            return launch_conv_mfma<CFG_L3_C1, false, false>(conv_args(m->cc[cur3], wb + m->l3[i].c1, m->r3, nullptr, n), m->num_cus, s);
+        });
+        L.run(K_L3_ESP, px3 * (25 * 9 * 128 * 2), [&] {
+            return launch_conv_mfma<CFG_L3_BR, true, true>(conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n), m->num_cus, s);
+        });
+        cur3 = nxt;
+        set_stage("level3." + std::to_string(i), m->cc[cur3], 128);
+    }
+
+    // ---- b3 + classifier (+ br + up_l3)  (Model.py:368-370)
+    L.run(K_DEC1, px3 * (256 * CLS * 2) + px3 * (CLS * CLS * 4 * 2), [&] {
+        Dec1Args a{};
+        a.c0 = view(m->cc[0]);
+        a.clast = view(m->cc[cur3]);
+        a.b3 = wb + m->b3;
+        a.wcls = wb + m->wcls;
+        a.br = m->encoder_only ? nullptr : wb + m->br;
+        a.wup = m->encoder_only ? nullptr : wb + m->wup3;
+        a.out = view(m->o2c);
+        a.enc_logits = m->encoder_only ? logits : nullptr;
+        a.N = n;
+        hipLaunchKernelGGL(dec1_kernel<CLS>, dim3(blocks_for((long long)n * H3 * W3)), dim3(256), 0, s, a);
+        return GS_OK;
+    });
+    if (m->encoder_only)
+        return L.st;
+    set_stage("up_l3", m->o2c, CLS);
+
+    // ---- level3_C + cat + BR (Model.py:372-373)
+    L.run(K_DEC2, px2 * (131 * CLS * 2), [&] {
+        Dec2Args a{};
+        a.a1 = view(m->a1);
+        a.o2c = view(m->o2c);
+        a.w3c = wb + m->w3c;
+        a.br = wb + m->cbr0;
+        a.t = view(m->tt);
+        a.N = n;
+        hipLaunchKernelGGL(dec2_kernel<CLS>, dim3(blocks_for((long long)n * H2 * W2)), dim3(256), 0, s, a);
+        return GS_OK;
+    });
+    set_stage("combine_t", m->tt, 2 * CLS);
+    // ---- CBR(2c,c,3) + up_l2 (Model.py:373)
+    L.run(K_DEC3, px2 * (2 * CLS * 9 * CLS * 2) + px2 * (CLS * CLS * 4 * 2), [&] {
+        Dec3Args a{};
+        a.t = view(m->tt);
+        a.wc = wb + m->wcc;
+        a.bnc = wb + m->bncc;
+        a.wup = wb + m->wup2;
+        a.bnu = wb + m->bnu2;
+        a.e = view(m->ee);
+        a.N = n;
+        hipLaunchKernelGGL(dec3_kernel<CLS>, dim3(blocks_for((long long)n * H2 * W2)), dim3(256), 0, s, a);
+        return GS_OK;
+    });
+    set_stage("up_l2", m->ee, CLS);
+    // ---- conv CBR(19+c,c,3) + classifier deconv + argmax + counts (Model.py:375-377, VisualizeResults_iou.py:128,151-155)
+    if (hist) {
+        if (hipMemsetAsync(hist, 0, sizeof(unsigned long long) * n * CLS, s) != hipSuccess) {
+            set_error("hipMemsetAsync(hist) failed");
+            return GS_ERR_HIP;
+        }
+    }
+    L.run(K_DEC4, px1 * ((19 + CLS) * 9 * CLS * 2) + px1 * (CLS * CLS * 4 * 2), [&] {
+        Dec4Args a{};
+        a.e = view(m->ee);
+        a.a0 = view(m->a0);
+        a.wc = wb + m->wconv;
+        a.bnc = wb + m->bnconv;
+        a.wcl = wb + m->wclassifier;
+        a.logits = logits;
+        a.mask = mask;
+        a.hist = hist;
+        a.N = n;
+        hipLaunchKernelGGL(dec4_kernel<CLS>, dim3(blocks_for((long long)H1 * W1), n), dim3(256), 0, s, a);
+        return GS_OK;
+    });
+    return L.st;
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+// ==========================================================================================
+extern "C" {
+
+const char *gs_last_error(void) { return g_err.c_str(); }
+int gs_abi_version(void) { return 1; }
+
+struct gs_espnet {
+    Model m;
+};
+
+gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_layers, int classes, int p, int q,
+                           int encoder_only, gs_espnet **out)
+{
+    GS_REQUIRE(blob && table && out && n_layers > 0, "gs_espnet_create: null argument");
+    GS_REQUIRE(p >= 0 && q >= 0, "gs_espnet_create: p and q must be non-negative");
+    if (classes != 5) {
+        set_error("gs_espnet_create: kernels are instantiated for classes=5 only (got %d)", classes);
+        return GS_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("gs_espnet_create: no HIP device visible");
+        return GS_ERR_NODEVICE;
+    }
+    std::unique_ptr<gs_espnet> h(new gs_espnet());
+    Model &m = h->m;
+    m.classes = classes;
+    m.p = p;
+    m.q = q;
+    m.encoder_only = encoder_only != 0;
+    GS_HIP(hipGetDevice(&m.device));
+    hipDeviceProp_t prop;
+    GS_HIP(hipGetDeviceProperties(&prop, m.device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("gs_espnet_create: device %d is %s; this library is built for gfx950 only", m.device, prop.gcnArchName);
+        return GS_ERR_NODEVICE;
+    }
+    m.num_cus = prop.multiProcessorCount;
+
+    WeightTable t;
+    t.blob = blob;
+    for (int i = 0; i < n_layers; ++i)
+        t.by_name[std::string(table[i].name)] = &table[i];
+    const std::string e = m.encoder_only ? "" : "encoder.";
+    const int c = classes;
+    BlobBuilder bb;
+    std::vector<float> tmp(3 * 256);
+
+    const float *w;
+    if (!(w = t.get(e + "level1.conv.weight", {16, 3, 3, 3}))) return GS_ERR_INVALID;
+    m.w1 = bb.push(w, 432);
+    if (!fold_bn(t, e + "level1.bn", e + "level1.act", 16, tmp.data())) return GS_ERR_INVALID;
+    m.bn1 = bb.push(tmp.data(), 48);
+    if (!fold_bn(t, e + "b1.bn", e + "b1.act", 19, tmp.data())) return GS_ERR_INVALID;
+    m.b1 = bb.push(tmp.data(), 57);
+    if (!pack_block(t, bb, e + "level2_0", true, 2, m.l2_0)) return GS_ERR_INVALID;
+    m.l2.resize(p);
+    for (int i = 0; i < p; ++i)
+        if (!pack_block(t, bb, e + "level2." + std::to_string(i), false, 2, m.l2[i])) return GS_ERR_INVALID;
+    if (!fold_bn(t, e + "b2.bn", e + "b2.act", 131, tmp.data())) return GS_ERR_INVALID;
+    m.b2 = bb.push(tmp.data(), 393);
+    if (!pack_block(t, bb, e + "level3_0", true, 3, m.l3_0)) return GS_ERR_INVALID;
+    m.l3.resize(q);
+    for (int i = 0; i < q; ++i)
+        if (!pack_block(t, bb, e + "level3." + std::to_string(i), false, 3, m.l3[i])) return GS_ERR_INVALID;
+    if (!fold_bn(t, e + "b3.bn", e + "b3.act", 256, tmp.data())) return GS_ERR_INVALID;
+    m.b3 = bb.push(tmp.data(), 768);
+    if (!(w = t.get(e + "classifier.conv.weight", {c, 256, 1, 1}))) return GS_ERR_INVALID;
+    m.wcls = bb.push(w, (size_t)c * 256);
+    if (!m.encoder_only) {
+        if (!fold_bn(t, "br", "", c, tmp.data(), false)) return GS_ERR_INVALID;
+        m.br = bb.push(tmp.data(), 2 * c);
+        if (!(w = t.get("up_l3.0.weight", {c, c, 2, 2}))) return GS_ERR_INVALID;
+        m.wup3 = bb.push(w, (size_t)c * c * 4);
+        if (!(w = t.get("level3_C.conv.weight", {c, 131, 1, 1}))) return GS_ERR_INVALID;
+        m.w3c = bb.push(w, (size_t)c * 131);
+        if (!fold_bn(t, "combine_l2_l3.0.bn", "combine_l2_l3.0.act", 2 * c, tmp.data())) return GS_ERR_INVALID;
+        m.cbr0 = bb.push(tmp.data(), 6 * c);
+        if (!(w = t.get("combine_l2_l3.1.conv.weight", {c, 2 * c, 3, 3}))) return GS_ERR_INVALID;
+        m.wcc = bb.push(w, (size_t)c * 2 * c * 9);
+        if (!fold_bn(t, "combine_l2_l3.1.bn", "combine_l2_l3.1.act", c, tmp.data())) return GS_ERR_INVALID;
+        m.bncc = bb.push(tmp.data(), 3 * c);
+        if (!(w = t.get("up_l2.0.weight", {c, c, 2, 2}))) return GS_ERR_INVALID;
+        m.wup2 = bb.push(w, (size_t)c * c * 4);
+        if (!fold_bn(t, "up_l2.1.bn", "up_l2.1.act", c, tmp.data())) return GS_ERR_INVALID;
+        m.bnu2 = bb.push(tmp.data(), 3 * c);
+        if (!(w = t.get("conv.conv.weight", {c, 19 + c, 3, 3}))) return GS_ERR_INVALID;
+        m.wconv = bb.push(w, (size_t)c * (19 + c) * 9);
+        if (!fold_bn(t, "conv.bn", "conv.act", c, tmp.data())) return GS_ERR_INVALID;
+        m.bnconv = bb.push(tmp.data(), 3 * c);
+        if (!(w = t.get("classifier.weight", {c, c, 2, 2}))) return GS_ERR_INVALID;
+        m.wclassifier = bb.push(w, (size_t)c * c * 4);
+    }
+    bb.reserve(64);   // tail guard for float4 staging reads
+    GS_HIP(hipMalloc(reinterpret_cast<void **>(&m.dblob), bb.data.size() * sizeof(float)));
+    GS_HIP(hipMemcpy(m.dblob, bb.data.data(), bb.data.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = h.release();
+    return GS_OK;
+}
+
+void gs_espnet_destroy(gs_espnet *h)
+{
+    if (!h)
+        return;
+    hipDeviceSynchronize();
+    for (auto &ev : h->m.events) {
+        hipEventDestroy(ev.a);
+        hipEventDestroy(ev.b);
+    }
+    if (h->m.ws) hipFree(h->m.ws);
+    if (h->m.prob) hipFree(h->m.prob);
+    if (h->m.dblob) hipFree(h->m.dblob);
+    delete h;
+}
+
+static gs_status check_shape(int n, int height, int width)
+{
+    GS_REQUIRE(n > 0, "batch size must be positive (got %d)", n);
+    GS_REQUIRE(height >= 8 && width >= 8 && height % 8 == 0 && width % 8 == 0,
+               "tile size must be a positive multiple of 8 in both dimensions (got %dx%d)", height, width);
+    return GS_OK;
+}
+
+gs_status gs_espnet_reserve(gs_espnet *h, int n, int height, int width)
+{
+    GS_REQUIRE(h, "null handle");
+    gs_status st = check_shape(n, height, width);
+    if (st != GS_OK) return st;
+    return layout_workspace(&h->m, n, height, width);
+}
+
+gs_status gs_espnet_forward(gs_espnet *h, const void *in, int in_format, int n, int height, int width,
+                            const float mean[3], const float std[3], float *logits, uint8_t *mask,
+                            unsigned long long *hist, void *hip_stream)
+{
+    GS_REQUIRE(h && in, "gs_espnet_forward: null handle or input");
+    gs_status st = check_shape(n, height, width);
+    if (st != GS_OK) return st;
+    GS_REQUIRE(in_format == GS_IN_U8_BGR_NHWC || in_format == GS_IN_F32_NCHW, "unknown input format %d", in_format);
+    GS_REQUIRE(in_format != GS_IN_U8_BGR_NHWC || (mean && std), "uint8 input needs mean and std");
+    Model &m = h->m;
+    if (m.encoder_only) {
+        GS_REQUIRE(logits && !mask && !hist, "ESPNet-C handle: only the 1/8-scale logits output exists");
+    } else {
+        GS_REQUIRE(logits || mask, "nothing to compute: logits and mask are both NULL");
+        GS_REQUIRE(!hist || mask, "hist requires the mask output");
+    }
+    if (in_format == GS_IN_U8_BGR_NHWC)
+        for (int i = 0; i < 3; ++i)
+            GS_REQUIRE(std[i] != 0.0f, "std[%d] is zero", i);
+    st = layout_workspace(&m, n, height, width);
+    if (st != GS_OK) return st;
+    return forward_impl<5>(&m, in, in_format, n, height, width, mean, std, logits, mask, hist,
+                           static_cast<hipStream_t>(hip_stream));
+}
+
+gs_status gs_espnet_read_stage(gs_espnet *h, const char *stage, int image, float *dst, size_t cap, int dims[3])
+{
+    GS_REQUIRE(h && stage && dims, "gs_espnet_read_stage: null argument");
+    Model &m = h->m;
+    auto it = m.stages.find(stage);
+    GS_REQUIRE(it != m.stages.end(), "stage '%s' was not produced by the last forward", stage);
+    GS_REQUIRE(image >= 0 && image < m.last_n, "image index %d out of range", image);
+    const Act &a = it->second.first;
+    const int C = it->second.second;
+    dims[0] = C;
+    dims[1] = a.H;
+    dims[2] = a.W;
+    const size_t count = (size_t)C * a.H * a.W;
+    if (!dst)
+        return GS_OK;
+    GS_REQUIRE(cap >= count, "destination too small for stage '%s'", stage);
+    float *tmp = nullptr;
+    GS_HIP(hipMalloc(reinterpret_cast<void **>(&tmp), count * sizeof(float)));
+    hipLaunchKernelGGL(unpad_kernel, dim3(blocks_for((long long)count)), dim3(256), 0, 0, view(a), image, C, tmp);
+    hipError_t e = hipMemcpy(dst, tmp, count * sizeof(float), hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    GS_HIP(e);
+    return GS_OK;
+}
+
+gs_status gs_espnet_profile_enable(gs_espnet *h, int on)
+{
+    GS_REQUIRE(h, "null handle");
+    h->m.profile = on != 0;
+    return GS_OK;
+}
+
+gs_status gs_espnet_profile_read(gs_espnet *h, gs_kernel_time *out, int cap, int *n_out)
+{
+    GS_REQUIRE(h && n_out, "null argument");
+    Model &m = h->m;
+    for (auto &ev : m.events) {
+        GS_HIP(hipEventSynchronize(ev.b));
+        float ms = 0.0f;
+        GS_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
+        m.prof_ms[ev.k] += ms;
+        m.prof_launches[ev.k] += 1;
+        hipEventDestroy(ev.a);
+        hipEventDestroy(ev.b);
+    }
+    m.events.clear();
+    int k = 0;
+    for (int i = 0; i < K_COUNT && out && k < cap; ++i) {
+        if (!m.prof_launches[i])
+            continue;
+        std::snprintf(out[k].name, sizeof out[k].name, "%s", kKernelNames[i]);
+        out[k].total_ms = m.prof_ms[i];
+        out[k].launches = m.prof_launches[i];
+        out[k].flops_per_tile = m.prof_flops[i];
+        ++k;
+    }
+    *n_out = k;
+    for (int i = 0; i < K_COUNT; ++i) {
+        m.prof_ms[i] = 0;
+        m.prof_launches[i] = 0;
+    }
+    return GS_OK;
+}
+
+gs_status gs_espnet_ensemble_forward(gs_espnet *const *models, int n_models, const void *in_u8, int n, int height,
+                                     int width, const float *means, const float *stds, uint8_t *mask,
+                                     unsigned long long *hist, void *hip_stream)
+{
+    GS_REQUIRE(models && n_models > 0 && in_u8 && means && stds && mask, "gs_espnet_ensemble_forward: null argument");
+    gs_status st = check_shape(n, height, width);
+    if (st != GS_OK) return st;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    Model &m0 = models[0]->m;
+    const size_t need = (size_t)n * 5 * height * width * sizeof(float) * 2;   // [logits | prob]
+    if (m0.prob_bytes < need) {
+        if (m0.prob) GS_HIP(hipFree(m0.prob));
+        m0.prob = nullptr;
+        m0.prob_bytes = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&m0.prob), need) != hipSuccess) {
+            set_error("ensemble scratch allocation of %zu bytes failed", need);
+            return GS_ERR_NOMEM;
+        }
+        m0.prob_bytes = need;
+    }
+    float *lg = m0.prob, *prob = m0.prob + (size_t)n * 5 * height * width;
+    const long long npix = (long long)height * width;
+    for (int k = 0; k < n_models; ++k) {
+        GS_REQUIRE(models[k] && !models[k]->m.encoder_only, "ensemble member %d is not a full ESPNet", k);
+        st = gs_espnet_forward(models[k], in_u8, GS_IN_U8_BGR_NHWC, n, height, width, means + 3 * k, stds + 3 * k, lg,
+                               nullptr, nullptr, hip_stream);
+        if (st != GS_OK) return st;
+        hipLaunchKernelGGL(softmax_accum_kernel<5>, dim3(blocks_for(npix * n)), dim3(256), 0, s, lg, prob, npix, npix * n,
+                           1.0f / (float)n_models, k == 0 ? 1 : 0);
+    }
+    if (hist) GS_HIP(hipMemsetAsync(hist, 0, sizeof(unsigned long long) * n * 5, s));
+    hipLaunchKernelGGL(argmax_hist_kernel<5>, dim3(blocks_for(npix), n), dim3(256), 0, s, prob, mask, hist, (int)npix);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles, int height, int width,
+                                 const float mean[3], const float std[3], int batch, uint8_t *masks,
+                                 unsigned long long *hist)
+{
+    GS_REQUIRE(h && tiles && masks && mean && std, "gs_espnet_segment_host: null argument");
+    GS_REQUIRE(n_tiles > 0 && batch > 0, "n_tiles and batch must be positive");
+    gs_status st = check_shape(batch, height, width);
+    if (st != GS_OK) return st;
+    if (batch > n_tiles) batch = n_tiles;
+    st = layout_workspace(&h->m, batch, height, width);
+    if (st != GS_OK) return st;
+    const size_t in_b = (size_t)height * width * 3, out_b = (size_t)height * width;
+    // two slots: while slot s computes, slot s^1 uploads the next batch and downloads the previous masks
+    struct Slot {
+        uint8_t *hin = nullptr, *hout = nullptr, *din = nullptr, *dout = nullptr;
+        unsigned long long *hh = nullptr, *dh = nullptr;
+        hipStream_t copy = nullptr;
+        hipEvent_t up = nullptr, done = nullptr, down = nullptr;
+        int first = -1, count = 0;
+    } sl[2];
+    hipStream_t compute = nullptr;
+    gs_status rc = GS_OK;
+    auto fail = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == GS_OK) {
+            set_error("%s failed: %s", what, hipGetErrorString(e));
+            rc = GS_ERR_HIP;
+        }
+        return e != hipSuccess;
+    };
+    fail(hipStreamCreateWithFlags(&compute, hipStreamNonBlocking), "hipStreamCreate");
+    for (auto &s : sl) {
+        fail(hipHostMalloc(reinterpret_cast<void **>(&s.hin), in_b * batch, hipHostMallocDefault), "hipHostMalloc");
+        fail(hipHostMalloc(reinterpret_cast<void **>(&s.hout), out_b * batch, hipHostMallocDefault), "hipHostMalloc");
+        fail(hipHostMalloc(reinterpret_cast<void **>(&s.hh), sizeof(unsigned long long) * 5 * batch, hipHostMallocDefault), "hipHostMalloc");
+        fail(hipMalloc(reinterpret_cast<void **>(&s.din), in_b * batch), "hipMalloc");
+        fail(hipMalloc(reinterpret_cast<void **>(&s.dout), out_b * batch), "hipMalloc");
+        fail(hipMalloc(reinterpret_cast<void **>(&s.dh), sizeof(unsigned long long) * 5 * batch), "hipMalloc");
+        fail(hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking), "hipStreamCreate");
+        fail(hipEventCreateWithFlags(&s.up, hipEventDisableTiming), "hipEventCreate");
+        fail(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
+        fail(hipEventCreateWithFlags(&s.down, hipEventDisableTiming), "hipEventCreate");
+    }
+    auto drain = [&](Slot &s) {   // wait for the slot's masks and hand them to the caller
+        if (s.first < 0 || rc != GS_OK)
+            return;
+        if (fail(hipEventSynchronize(s.down), "hipEventSynchronize")) return;
+        std::memcpy(masks + (size_t)s.first * out_b, s.hout, out_b * s.count);
+        if (hist) std::memcpy(hist + (size_t)s.first * 5, s.hh, sizeof(unsigned long long) * 5 * s.count);
+        s.first = -1;
+    };
+    int slot = 0;
+    for (int first = 0; first < n_tiles && rc == GS_OK; first += batch, slot ^= 1) {
+        Slot &s = sl[slot];
+        drain(s);   // the slot's previous batch must have left its pinned buffers
+        if (rc != GS_OK) break;
+        const int cnt = n_tiles - first < batch ? n_tiles - first : batch;
+        std::memcpy(s.hin, tiles + (size_t)first * in_b, in_b * cnt);
+        if (fail(hipMemcpyAsync(s.din, s.hin, in_b * cnt, hipMemcpyHostToDevice, s.copy), "H2D copy")) break;
+        fail(hipEventRecord(s.up, s.copy), "hipEventRecord");
+        fail(hipStreamWaitEvent(compute, s.up, 0), "hipStreamWaitEvent");
+        gs_status st2 = gs_espnet_forward(h, s.din, GS_IN_U8_BGR_NHWC, cnt, height, width, mean, std, nullptr, s.dout,
+                                          s.dh, compute);
+        if (st2 != GS_OK) { rc = st2; break; }
+        fail(hipEventRecord(s.done, compute), "hipEventRecord");
+        fail(hipStreamWaitEvent(s.copy, s.done, 0), "hipStreamWaitEvent");
+        fail(hipMemcpyAsync(s.hout, s.dout, out_b * cnt, hipMemcpyDeviceToHost, s.copy), "D2H copy");
+        fail(hipMemcpyAsync(s.hh, s.dh, sizeof(unsigned long long) * 5 * cnt, hipMemcpyDeviceToHost, s.copy), "D2H copy");
+        fail(hipEventRecord(s.down, s.copy), "hipEventRecord");
+        s.first = first;
+        s.count = cnt;
+    }
+    drain(sl[slot]);
+    drain(sl[slot ^ 1]);
+    hipDeviceSynchronize();
+    for (auto &s : sl) {
+        if (s.hin) hipHostFree(s.hin);
+        if (s.hout) hipHostFree(s.hout);
+        if (s.hh) hipHostFree(s.hh);
+        if (s.din) hipFree(s.din);
+        if (s.dout) hipFree(s.dout);
+        if (s.dh) hipFree(s.dh);
+        if (s.copy) hipStreamDestroy(s.copy);
+        if (s.up) hipEventDestroy(s.up);
+        if (s.done) hipEventDestroy(s.done);
+        if (s.down) hipEventDestroy(s.down);
+    }
+    if (compute) hipStreamDestroy(compute);
+    return rc;
+}
+
+}  // extern "C"

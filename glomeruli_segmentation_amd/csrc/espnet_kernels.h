@@ -1,0 +1,447 @@
+// Bandwidth-bound (non-GEMM) stages of the ESPNet forward as fused VALU kernels.  Each kernel
+// names the reference lines it fuses.  Weights are read with wave-uniform indices, so hipcc emits
+// scalar (SMEM) loads for them; activations are read coalesced along x.
+#pragma once
+#include "gs_internal.h"
+
+namespace gs {
+
+struct ActV {   // device-side view of gs::Act
+    float *base;
+    long long sn;
+    int sc, pitch, off;
+    int H, W;
+};
+static inline ActV view(const Act &a) { return ActV{a.base, a.sn, a.sc, a.pitch, a.off, a.H, a.W}; }
+
+__device__ __forceinline__ float *at(const ActV &t, int n, int c, int y, int x)
+{
+    return t.base + (long long)n * t.sn + (long long)c * t.sc + t.off + y * t.pitch + x;
+}
+// zero-padding read (conv / pool padding semantics)
+__device__ __forceinline__ float ldz(const ActV &t, int n, int c, int y, int x)
+{
+    return (y >= 0 && y < t.H && x >= 0 && x < t.W) ? *at(t, n, c, y, x) : 0.0f;
+}
+__device__ __forceinline__ float bn_prelu(float v, const float *bnp, int C, int c)
+{
+    v = v * bnp[c] + bnp[C + c];
+    return v > 0.0f ? v : bnp[2 * C + c] * v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stem: normalise -> level1 CBR(3,16,3,2) -> sample1 avg-pool -> cat -> b1 BR(19)
+// reference: VisualizeResults_iou.py:107-117, Model.py:346-350 (278-282), CBR :24-32, BR :47-54,
+// InputProjectionA :232-239.
+struct StemArgs {
+    const void *in;          // uint8 NHWC BGR or fp32 NCHW
+    float mean[3], std[3];
+    const float *w1;         // level1.conv.weight [16][3][3][3]
+    const float *bn1;        // level1 bn+act folded [3][16]
+    const float *b1;         // b1 folded [3][19]
+    ActV a0;                 // out: output0_cat, 19 channels, (H/2 x W/2)
+    ActV inp1;               // out: raw pooled input, 3 channels (feeds sample2's second pool)
+    int N, H, W;             // INPUT size
+};
+
+template <bool U8>
+__device__ __forceinline__ float stem_fetch(const StemArgs &a, int n, int c, int y, int x)
+{
+    if (y < 0 || y >= a.H || x < 0 || x >= a.W)
+        return 0.0f;   // padding acts on the normalised tensor
+    if (U8) {
+        float v = (float)static_cast<const unsigned char *>(a.in)[(((long long)n * a.H + y) * a.W + x) * 3 + c];
+        v = v - a.mean[c];     // same three fp32 roundings as numpy (VisualizeResults_iou.py:109,111,116)
+        v = v / a.std[c];
+        return v / 255.0f;
+    }
+    return static_cast<const float *>(a.in)[(((long long)n * 3 + c) * a.H + y) * a.W + x];
+}
+
+template <bool U8>
+__global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
+{
+    const int H1 = a.H / 2, W1 = a.W / 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.N * H1 * W1)
+        return;
+    const int x = (int)(idx % W1);
+    const int y = (int)((idx / W1) % H1);
+    const int n = (int)(idx / ((long long)W1 * H1));
+
+    float v[3][3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                v[c][ky][kx] = stem_fetch<U8>(a, n, c, 2 * y - 1 + ky, 2 * x - 1 + kx);
+
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    s = fmaf(a.w1[((o * 3 + c) * 3 + ky) * 3 + kx], v[c][ky][kx], s);
+        s = bn_prelu(s, a.bn1, 16, o);
+        *at(a.a0, n, o, y, x) = bn_prelu(s, a.b1, 19, o);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                s += v[c][ky][kx];
+        s = s / 9.0f;   // count_include_pad=True
+        *at(a.inp1, n, c, y, x) = s;
+        *at(a.a0, n, 16 + c, y, x) = bn_prelu(s, a.b1, 19, 16 + c);
+    }
+}
+
+// second AvgPool2d(3,2,1) of sample2.  reference: Model.py:232-239,348
+__global__ void __launch_bounds__(256) pool_kernel(const ActV in, const ActV out, int N, int C)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * C * out.H * out.W)
+        return;
+    const int x = (int)(idx % out.W);
+    const int y = (int)((idx / out.W) % out.H);
+    const int c = (int)((idx / ((long long)out.W * out.H)) % C);
+    const int n = (int)(idx / ((long long)out.W * out.H * C));
+    float s = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+            s += ldz(in, n, c, 2 * y - 1 + ky, 2 * x - 1 + kx);
+    *at(out, n, c, y, x) = s / 9.0f;
+}
+
+// b2: cat([output1, output1_0, inp2]) -> BR(131).  reference: Model.py:359 (291)
+__global__ void __launch_bounds__(256)
+cat_b2_kernel(const ActV o1, const ActV o10, const ActV inp2, const float *bnp, const ActV out, int N)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * 131 * out.H * out.W)
+        return;
+    const int x = (int)(idx % out.W);
+    const int y = (int)((idx / out.W) % out.H);
+    const int c = (int)((idx / ((long long)out.W * out.H)) % 131);
+    const int n = (int)(idx / ((long long)out.W * out.H * 131));
+    const float v = c < 64 ? *at(o1, n, c, y, x) : c < 128 ? *at(o10, n, c - 64, y, x) : *at(inp2, n, c - 128, y, x);
+    *at(out, n, c, y, x) = bn_prelu(v, bnp, 131, c);
+}
+
+// b3 -> encoder classifier -> (br BN -> up_l3 deconv).  One thread per 1/8-scale pixel.
+// reference: Model.py:368-370 (b3: cat([output2_0, output2]) -> BR(256); classifier C(256,classes,1);
+// br = BatchNorm2d(classes); up_l3 = ConvTranspose2d(classes,classes,2,stride=2)).
+struct Dec1Args {
+    ActV c0, clast;      // output2_0, output2 (128 channels each)
+    const float *b3;     // folded [3][256]
+    const float *wcls;   // encoder.classifier.conv.weight [CLS][256]
+    const float *br;     // folded br scale/shift [2][CLS]
+    const float *wup;    // up_l3.0.weight [CLS][CLS][2][2]
+    ActV out;            // output2_c: CLS channels at 1/4 scale
+    float *enc_logits;   // encoder-only mode: [N][CLS][H3][W3], else null
+    int N;
+};
+
+template <int CLS>
+__global__ void __launch_bounds__(256) dec1_kernel(const Dec1Args a)
+{
+    const int H3 = a.c0.H, W3 = a.c0.W;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.N * H3 * W3)
+        return;
+    const int x = (int)(idx % W3);
+    const int y = (int)((idx / W3) % H3);
+    const int n = (int)(idx / ((long long)W3 * H3));
+    float s[CLS];
+#pragma unroll
+    for (int k = 0; k < CLS; ++k)
+        s[k] = 0.0f;
+    for (int c = 0; c < 256; ++c) {
+        const float raw = c < 128 ? *at(a.c0, n, c, y, x) : *at(a.clast, n, c - 128, y, x);
+        const float v = bn_prelu(raw, a.b3, 256, c);
+#pragma unroll
+        for (int k = 0; k < CLS; ++k)
+            s[k] = fmaf(a.wcls[k * 256 + c], v, s[k]);
+    }
+    if (a.enc_logits) {
+#pragma unroll
+        for (int k = 0; k < CLS; ++k)
+            a.enc_logits[(((long long)n * CLS + k) * H3 + y) * W3 + x] = s[k];
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < CLS; ++k)
+        s[k] = s[k] * a.br[k] + a.br[CLS + k];
+#pragma unroll
+    for (int o = 0; o < CLS; ++o)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float t = 0.0f;
+#pragma unroll
+                for (int i = 0; i < CLS; ++i)
+                    t = fmaf(s[i], a.wup[((i * CLS + o) * 2 + dy) * 2 + dx], t);
+                *at(a.out, n, o, 2 * y + dy, 2 * x + dx) = t;
+            }
+}
+
+// level3_C 1x1 on output1_cat, cat with output2_c, BR(2*classes).  One thread per 1/4-scale pixel.
+// reference: Model.py:372-373 (level3_C = C(131,classes,1); combine_l2_l3[0] = BR(2*classes))
+struct Dec2Args {
+    ActV a1;             // output1_cat (131 channels)
+    ActV o2c;            // output2_c (CLS)
+    const float *w3c;    // level3_C.conv.weight [CLS][131]
+    const float *br;     // combine_l2_l3.0 folded [3][2*CLS]
+    ActV t;              // out: 2*CLS channels
+    int N;
+};
+
+template <int CLS>
+__global__ void __launch_bounds__(256) dec2_kernel(const Dec2Args a)
+{
+    const int H2 = a.a1.H, W2 = a.a1.W;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.N * H2 * W2)
+        return;
+    const int x = (int)(idx % W2);
+    const int y = (int)((idx / W2) % H2);
+    const int n = (int)(idx / ((long long)W2 * H2));
+    float s[CLS];
+#pragma unroll
+    for (int k = 0; k < CLS; ++k)
+        s[k] = 0.0f;
+    for (int c = 0; c < 131; ++c) {
+        const float v = *at(a.a1, n, c, y, x);
+#pragma unroll
+        for (int k = 0; k < CLS; ++k)
+            s[k] = fmaf(a.w3c[k * 131 + c], v, s[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < CLS; ++k) {
+        *at(a.t, n, k, y, x) = bn_prelu(s[k], a.br, 2 * CLS, k);
+        *at(a.t, n, CLS + k, y, x) = bn_prelu(*at(a.o2c, n, k, y, x), a.br, 2 * CLS, CLS + k);
+    }
+}
+
+// combine_l2_l3[1] CBR(2*classes,classes,3) -> up_l2 deconv -> BR(classes).  One thread per
+// 1/4-scale pixel.  reference: Model.py:373 (335,337)
+struct Dec3Args {
+    ActV t;              // 2*CLS channels
+    const float *wc;     // combine_l2_l3.1.conv.weight [CLS][2*CLS][3][3]
+    const float *bnc;    // combine_l2_l3.1 bn+act folded [3][CLS]
+    const float *wup;    // up_l2.0.weight [CLS][CLS][2][2]
+    const float *bnu;    // up_l2.1 folded [3][CLS]
+    ActV e;              // out: comb_l2_l3 at 1/2 scale, CLS channels
+    int N;
+};
+
+template <int CLS>
+__global__ void __launch_bounds__(256) dec3_kernel(const Dec3Args a)
+{
+    const int H2 = a.t.H, W2 = a.t.W;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.N * H2 * W2)
+        return;
+    const int x = (int)(idx % W2);
+    const int y = (int)((idx / W2) % H2);
+    const int n = (int)(idx / ((long long)W2 * H2));
+    float s[CLS];
+#pragma unroll
+    for (int k = 0; k < CLS; ++k)
+        s[k] = 0.0f;
+    for (int c = 0; c < 2 * CLS; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float v = ldz(a.t, n, c, y - 1 + ky, x - 1 + kx);
+#pragma unroll
+                for (int k = 0; k < CLS; ++k)
+                    s[k] = fmaf(a.wc[((k * 2 * CLS + c) * 3 + ky) * 3 + kx], v, s[k]);
+            }
+#pragma unroll
+    for (int k = 0; k < CLS; ++k)
+        s[k] = bn_prelu(s[k], a.bnc, CLS, k);
+#pragma unroll
+    for (int o = 0; o < CLS; ++o)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float t = 0.0f;
+#pragma unroll
+                for (int i = 0; i < CLS; ++i)
+                    t = fmaf(s[i], a.wup[((i * CLS + o) * 2 + dy) * 2 + dx], t);
+                *at(a.e, n, o, 2 * y + dy, 2 * x + dx) = bn_prelu(t, a.bnu, CLS, o);
+            }
+}
+
+// conv CBR(19+classes,classes,3) on cat([comb_l2_l3, output0_cat]) -> classifier deconv -> logits
+// -> first-max argmax -> uint8 mask -> per-class pixel counts.  One thread per 1/2-scale pixel
+// (= a 2x2 block of output pixels).
+// reference: Model.py:375-377; VisualizeResults_iou.py:128 (argmax), :151-155 (counts)
+struct Dec4Args {
+    ActV e;              // comb_l2_l3 (CLS channels)
+    ActV a0;             // output0_cat (19 channels)
+    const float *wc;     // conv.conv.weight [CLS][CLS+19][3][3]
+    const float *bnc;    // conv bn+act folded [3][CLS]
+    const float *wcl;    // classifier.weight [CLS][CLS][2][2]
+    float *logits;       // [N][CLS][H][W] or null
+    unsigned char *mask; // [N][H][W] or null
+    unsigned long long *hist;   // [N][CLS] or null
+    int N;
+};
+
+template <int CLS>
+__global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
+{
+    __shared__ unsigned int lhist[CLS];
+    const int H1 = a.e.H, W1 = a.e.W;
+    const int H = 2 * H1, W = 2 * W1;
+    // one block never straddles two images: grid.y = image
+    const int n = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (a.hist) {
+        if (threadIdx.x < CLS)
+            lhist[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    if (idx < H1 * W1) {
+        const int x = idx % W1;
+        const int y = idx / W1;
+        float s[CLS];
+#pragma unroll
+        for (int k = 0; k < CLS; ++k)
+            s[k] = 0.0f;
+        for (int c = 0; c < CLS + 19; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float v = c < CLS ? ldz(a.e, n, c, y - 1 + ky, x - 1 + kx)
+                                            : ldz(a.a0, n, c - CLS, y - 1 + ky, x - 1 + kx);
+#pragma unroll
+                    for (int k = 0; k < CLS; ++k)
+                        s[k] = fmaf(a.wc[((k * (CLS + 19) + c) * 3 + ky) * 3 + kx], v, s[k]);
+                }
+#pragma unroll
+        for (int k = 0; k < CLS; ++k)
+            s[k] = bn_prelu(s[k], a.bnc, CLS, k);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            unsigned char m[2];
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float best = 0.0f;
+                int bi = 0;
+#pragma unroll
+                for (int o = 0; o < CLS; ++o) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < CLS; ++i)
+                        t = fmaf(s[i], a.wcl[((i * CLS + o) * 2 + dy) * 2 + dx], t);
+                    if (a.logits)
+                        a.logits[(((long long)n * CLS + o) * H + 2 * y + dy) * W + 2 * x + dx] = t;
+                    if (o == 0 || t > best) {   // strict '>' : first maximum wins
+                        best = t;
+                        bi = o;
+                    }
+                }
+                m[dx] = (unsigned char)bi;
+                if (a.hist)
+                    atomicAdd(&lhist[bi], 1u);
+            }
+            if (a.mask)
+                *reinterpret_cast<uchar2 *>(a.mask + ((long long)n * H + 2 * y + dy) * W + 2 * x) = make_uchar2(m[0], m[1]);
+        }
+    }
+    if (a.hist) {
+        __syncthreads();
+        if (threadIdx.x < CLS && lhist[threadIdx.x])
+            atomicAdd(&a.hist[(long long)n * CLS + threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
+    }
+}
+
+// ensemble helpers (cfg 5): prob += softmax(logits) * w ; final argmax + counts
+template <int CLS>
+__global__ void __launch_bounds__(256) softmax_accum_kernel(const float *logits, float *prob, long long npix_per_img,
+                                                            long long total, float wgt, int first)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total)
+        return;
+    const long long n = idx / npix_per_img, p = idx % npix_per_img;
+    float v[CLS], mx = -3.4e38f;
+#pragma unroll
+    for (int k = 0; k < CLS; ++k) {
+        v[k] = logits[(n * CLS + k) * npix_per_img + p];
+        mx = fmaxf(mx, v[k]);
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < CLS; ++k) {
+        v[k] = expf(v[k] - mx);
+        sum += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < CLS; ++k) {
+        float *q = prob + (n * CLS + k) * npix_per_img + p;
+        const float add = v[k] / sum * wgt;
+        *q = first ? add : *q + add;
+    }
+}
+
+template <int CLS>
+__global__ void __launch_bounds__(256) argmax_hist_kernel(const float *prob, unsigned char *mask, unsigned long long *hist,
+                                                          int npix_per_img)
+{
+    __shared__ unsigned int lhist[CLS];
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < CLS)
+        lhist[threadIdx.x] = 0;
+    __syncthreads();
+    if (p < npix_per_img) {
+        float best = 0.0f;
+        int bi = 0;
+#pragma unroll
+        for (int k = 0; k < CLS; ++k) {
+            const float t = prob[((long long)n * CLS + k) * npix_per_img + p];
+            if (k == 0 || t > best) {
+                best = t;
+                bi = k;
+            }
+        }
+        mask[(long long)n * npix_per_img + p] = (unsigned char)bi;
+        atomicAdd(&lhist[bi], 1u);
+    }
+    __syncthreads();
+    if (hist && threadIdx.x < CLS && lhist[threadIdx.x])
+        atomicAdd(&hist[(long long)n * CLS + threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
+}
+
+// copy one image of a padded activation to a dense CHW buffer (debug / tests)
+__global__ void __launch_bounds__(256) unpad_kernel(const ActV t, int n, int C, float *dst)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)C * t.H * t.W)
+        return;
+    const int x = (int)(idx % t.W);
+    const int y = (int)((idx / t.W) % t.H);
+    const int c = (int)(idx / ((long long)t.W * t.H));
+    dst[idx] = *at(t, n, c, y, x);
+}
+
+}  // namespace gs

@@ -1,0 +1,175 @@
+"""Host-side owner of a ``gs_espnet`` handle: packs a reference state_dict into the weight blob
+the C ABI takes and exposes the hot-path calls on torch HIP tensors.
+
+torch is used for device memory and streams only; all arithmetic happens in libglomseg.so.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _to_numpy(v):
+    if isinstance(v, torch.Tensor):
+        return v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+def pack_state_dict(state_dict):
+    """state_dict (name -> tensor/array) -> (fp32 blob, LayerDesc array).  Integer buffers such as
+    BatchNorm's num_batches_tracked are not arithmetic inputs and are skipped.
+    Replaces torch.load + load_state_dict at VisualizeResults_iou.py:272,279."""
+    items = []
+    total = 0
+    for name, v in state_dict.items():
+        a = _to_numpy(v)
+        if a.dtype.kind != "f":
+            continue
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.ndim > 4:
+            raise ValueError("tensor %s has %d dims" % (name, a.ndim))
+        items.append((name, a, total))
+        total += a.size
+    blob = np.empty(total, dtype=np.float32)
+    table = (_lib.LayerDesc * len(items))()
+    for i, (name, a, off) in enumerate(items):
+        blob[off:off + a.size] = a.ravel()
+        enc = name.encode()
+        if len(enc) >= 96:
+            raise ValueError("tensor name too long: " + name)
+        table[i].name = enc
+        table[i].offset = off
+        table[i].ndim = a.ndim
+        for d in range(a.ndim):
+            table[i].shape[d] = a.shape[d]
+    return blob, table
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class EspnetEngine:
+    """One model on one GPU.  ``encoder_only`` builds ESPNet-C (keys without the 'encoder.' prefix)."""
+
+    def __init__(self, state_dict, classes=5, p=2, q=8, encoder_only=False, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("EspnetEngine needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU path in this build")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else
+                                   torch.device(device).index or 0)
+        self.classes, self.p, self.q, self.encoder_only = classes, p, q, encoder_only
+        blob, table = pack_state_dict(state_dict)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gs_espnet_create(blob.ctypes.data_as(ctypes.c_void_p), table, len(table), classes, p,
+                                                 q, 1 if encoder_only else 0, ctypes.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            with torch.cuda.device(self.device):
+                self.lib.gs_espnet_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ hot path
+    def reserve(self, n, height, width):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gs_espnet_reserve(self.handle, n, height, width))
+
+    def forward_logits(self, x):
+        """fp32 [N,3,H,W] on the GPU -> logits [N,classes,H,W] ([N,classes,H/8,W/8] for ESPNet-C).
+        The nn.Module.forward replacement (Model.py:341 / :273)."""
+        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3 or not x.is_cuda:
+            raise ValueError("expected a float32 [N,3,H,W] tensor on the GPU")
+        x = x.contiguous()
+        n, _, h, w = x.shape
+        oh, ow = (h // 8, w // 8) if self.encoder_only else (h, w)
+        out = torch.empty((n, self.classes, oh, ow), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.gs_espnet_forward(self.handle, x.data_ptr(), _lib.GS_IN_F32_NCHW, n, h, w, None, None,
+                                                  out.data_ptr(), None, None, _stream_ptr(x.device)))
+        return out
+
+    def segment(self, tiles_u8, mean, std, want_logits=False, want_hist=True, out_mask=None, out_hist=None):
+        """uint8 BGR [N,H,W,3] on the GPU -> (mask uint8 [N,H,W], counts int64 [N,classes], logits|None).
+        One pass of VisualizeResults_iou.py:107-128,151-155 for a batch."""
+        if tiles_u8.dtype != torch.uint8 or tiles_u8.dim() != 4 or tiles_u8.shape[3] != 3 or not tiles_u8.is_cuda:
+            raise ValueError("expected a uint8 [N,H,W,3] tensor on the GPU")
+        if self.encoder_only:
+            raise ValueError("segment() needs the full ESPNet (decoder)")
+        tiles_u8 = tiles_u8.contiguous()
+        n, h, w, _ = tiles_u8.shape
+        dev = tiles_u8.device
+        mask = out_mask if out_mask is not None else torch.empty((n, h, w), dtype=torch.uint8, device=dev)
+        hist = None
+        if want_hist:
+            hist = out_hist if out_hist is not None else torch.empty((n, self.classes), dtype=torch.int64, device=dev)
+        logits = torch.empty((n, self.classes, h, w), dtype=torch.float32, device=dev) if want_logits else None
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.gs_espnet_forward(
+                self.handle, tiles_u8.data_ptr(), _lib.GS_IN_U8_BGR_NHWC, n, h, w, _lib.fptr3(mean), _lib.fptr3(std),
+                logits.data_ptr() if want_logits else None, mask.data_ptr(),
+                hist.data_ptr() if want_hist else None, _stream_ptr(dev)))
+        return mask, hist, logits
+
+    def segment_host(self, tiles, mean, std, batch=32, want_hist=True):
+        """numpy uint8 [T,H,W,3] in host memory -> (masks [T,H,W], counts [T,classes]) through the
+        pinned double-buffered H2D / compute / D2H pipeline of the library."""
+        tiles = np.ascontiguousarray(tiles, dtype=np.uint8)
+        t, h, w, _ = tiles.shape
+        masks = np.empty((t, h, w), dtype=np.uint8)
+        hist = np.zeros((t, self.classes), dtype=np.uint64) if want_hist else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gs_espnet_segment_host(
+                self.handle, tiles.ctypes.data_as(ctypes.c_void_p), t, h, w, _lib.fptr3(mean), _lib.fptr3(std), batch,
+                masks.ctypes.data_as(ctypes.c_void_p), hist.ctypes.data_as(ctypes.c_void_p) if want_hist else None))
+        return masks, (hist.astype(np.int64) if want_hist else None)
+
+    # ------------------------------------------------------------------ test / bench hooks
+    def read_stage(self, name, image=0):
+        dims = (ctypes.c_int * 3)()
+        _lib.check(self.lib.gs_espnet_read_stage(self.handle, name.encode(), image, None, 0, ctypes.byref(dims)))
+        out = np.empty(tuple(dims), dtype=np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gs_espnet_read_stage(self.handle, name.encode(), image,
+                                                     out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(dims)))
+        return out
+
+    def profile(self, on):
+        _lib.check(self.lib.gs_espnet_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_read(self):
+        arr = (_lib.KernelTime * 32)()
+        n = ctypes.c_int()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gs_espnet_profile_read(self.handle, arr, 32, ctypes.byref(n)))
+        return [{"name": arr[i].name.decode(), "total_ms": arr[i].total_ms, "launches": arr[i].launches,
+                 "flops_per_tile": arr[i].flops_per_tile} for i in range(n.value)]
+
+
+def ensemble_segment(engines, tiles_u8, mean_stds):
+    """cfg 5: mean over models of softmax(logits_k) (each model with its own mean/std) -> argmax mask,
+    per-class counts.  The reference has no ensemble code; the definition is this build's."""
+    lib = _lib.load()
+    tiles_u8 = tiles_u8.contiguous()
+    n, h, w, _ = tiles_u8.shape
+    dev = tiles_u8.device
+    handles = (ctypes.c_void_p * len(engines))(*[e.handle for e in engines])
+    means = (ctypes.c_float * (3 * len(engines)))(*[float(v) for ms in mean_stds for v in ms[0]])
+    stds = (ctypes.c_float * (3 * len(engines)))(*[float(v) for ms in mean_stds for v in ms[1]])
+    mask = torch.empty((n, h, w), dtype=torch.uint8, device=dev)
+    hist = torch.empty((n, engines[0].classes), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gs_espnet_ensemble_forward(handles, len(engines), tiles_u8.data_ptr(), n, h, w, means, stds,
+                                                  mask.data_ptr(), hist.data_ptr(), _stream_ptr(dev)))
+    return mask, hist

@@ -1,0 +1,136 @@
+/*
+ * glomseg.h -- C ABI of libglomseg.so: the MI355X (gfx950) replacement for the per-patch
+ * inference hot path of jinseikenai/glomeruli_segmentation.
+ *
+ * The reference has no native code; its "operator API" for this path is
+ * torch.nn.Module.__call__ on module/espnet/test/Model.py's ESPNet / ESPNet_Encoder
+ * (called at module/espnet/test/VisualizeResults_iou.py:123) and tf.Session.run on a frozen
+ * detector graph (module/faster-rcnn/detect_glomus_test.py:350-352).  These entry points are
+ * what a ctypes / cffi / pybind stub on the reference side binds instead.
+ *
+ * Conventions: plain pointers and sizes, no torch types.  Every function returns gs_status and
+ * never throws; gs_last_error() gives the message of the calling thread's last failure.
+ * Device pointers must belong to the HIP device that is current at the call.  A handle is bound
+ * to that device and is not thread-safe; work is stream-ordered on the hipStream_t passed in
+ * (NULL = the legacy default stream).
+ */
+#ifndef GLOMSEG_H
+#define GLOMSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gs_status {
+    GS_OK = 0,
+    GS_ERR_INVALID = 1,     /* bad argument / missing or mis-shaped weight tensor */
+    GS_ERR_HIP = 2,         /* a HIP runtime call failed */
+    GS_ERR_NOMEM = 3,
+    GS_ERR_UNSUPPORTED = 4, /* configuration the kernels are not built for */
+    GS_ERR_NODEVICE = 5     /* no gfx950 device visible */
+} gs_status;
+
+const char *gs_last_error(void);
+/* ABI version, bumped on any signature change. */
+int gs_abi_version(void);
+
+/* ------------------------------------------------------------------ weights
+ * One entry per state_dict tensor, named exactly as in models/espnet_fold*.pth
+ * (e.g. "encoder.level3.7.d16.conv.weight").  `offset` counts floats into `blob`.
+ * Replaces: torch.load + load_state_dict, VisualizeResults_iou.py:272,279. */
+typedef struct gs_layer_desc {
+    char name[96];
+    int64_t offset;
+    int32_t ndim;
+    int32_t shape[4];
+} gs_layer_desc;
+
+typedef struct gs_espnet gs_espnet;
+
+/* Build a model handle on the current HIP device from a host fp32 weight blob.
+ * classes/p/q as ESPNet(classes, p, q) (Model.py:311); encoder_only != 0 builds
+ * ESPNet_Encoder (ESPNet-C, Model.py:246) whose table uses keys without the "encoder." prefix. */
+gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_layers, int classes,
+                           int p, int q, int encoder_only, gs_espnet **out);
+void gs_espnet_destroy(gs_espnet *h);
+
+/* Pre-size the activation workspace for batches up to n tiles of h x w (both multiples of 8).
+ * Optional: forward grows the workspace on demand (which allocates, so call this first when the
+ * forward is to be captured in a hipGraph). */
+gs_status gs_espnet_reserve(gs_espnet *h, int n, int height, int width);
+
+typedef enum gs_input_format {
+    GS_IN_U8_BGR_NHWC = 0, /* what cv2.imread yields (VisualizeResults_iou.py:103); normalised on the fly */
+    GS_IN_F32_NCHW = 1     /* already-normalised tensor, the nn.Module.forward argument (Model.py:341) */
+} gs_input_format;
+
+/* One pass of the hot path over a batch of n tiles resident in device memory.
+ * Replaces VisualizeResults_iou.py:107-128 + :151-155 (normalise -> model(x) -> argmax -> counts).
+ *   in        device, format per in_format; mean/std (host, 3 floats, BGR) used only for U8 input
+ *   logits    device fp32 [n,classes,h,w] or NULL   (ESPNet-C: [n,classes,h/8,w/8])
+ *   mask      device uint8 [n,h,w] or NULL          (first maximum wins, torch semantics)
+ *   hist      device uint64 [n,classes] per-class pixel counts or NULL (requires the mask pass)
+ * At least one of logits/mask must be non-NULL. */
+gs_status gs_espnet_forward(gs_espnet *h, const void *in, int in_format, int n, int height, int width,
+                            const float mean[3], const float std[3], float *logits, uint8_t *mask,
+                            unsigned long long *hist, void *hip_stream);
+
+/* Host-to-host batch pipeline: n_tiles uint8 BGR tiles in (pageable or pinned) host memory are
+ * staged through pinned double buffers with hipMemcpyAsync on two streams, `batch` tiles per step,
+ * masks (and optional per-tile histograms) come back to host memory.  Replaces the whole loop
+ * VisualizeResults_iou.py:100-156 for a list of equal-size tiles. */
+gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles, int height, int width,
+                                 const float mean[3], const float std[3], int batch, uint8_t *masks,
+                                 unsigned long long *hist);
+
+/* 5-fold style ensemble (BASELINE cfg 5; definition in DESIGN.md): probability = mean over
+ * models of softmax(logits_k), each model with its own mean/std; writes argmax mask. */
+gs_status gs_espnet_ensemble_forward(gs_espnet *const *models, int n_models, const void *in_u8, int n,
+                                     int height, int width, const float *means /*[n_models*3]*/,
+                                     const float *stds /*[n_models*3]*/, uint8_t *mask,
+                                     unsigned long long *hist, void *hip_stream);
+
+/* Debug/test hook: copy one named intermediate activation of the LAST forward (image index
+ * `image`) to host memory as contiguous CHW fp32.  Names follow tests/golden stage names
+ * ("b1","level2_0","level2.0",...,"b2","level3_0","level3.7","up_l3","combine_t","up_l2",...).
+ * dims receives {C,H,W}.  cap counts floats. */
+gs_status gs_espnet_read_stage(gs_espnet *h, const char *stage, int image, float *dst, size_t cap,
+                               int dims[3]);
+
+/* Per-kernel timing with HIP events recorded on the launch stream.  While enabled every kernel of
+ * gs_espnet_forward is bracketed by an event pair; gs_espnet_profile_read synchronises and
+ * accumulates.  Used by bench.py for the roofline line. */
+typedef struct gs_kernel_time {
+    char name[64];
+    double total_ms;
+    int64_t launches;
+    double flops_per_tile; /* algorithmic (unpadded) FLOPs this kernel performs per launch per tile */
+} gs_kernel_time;
+gs_status gs_espnet_profile_enable(gs_espnet *h, int on);
+gs_status gs_espnet_profile_read(gs_espnet *h, gs_kernel_time *out, int cap, int *n_out);
+
+/* ------------------------------------------------------------------ detector-side primitives
+ * The detector network is an external TF1 frozen graph that is not in the reference
+ * (detect_glomus_test.py:419-427), so there is no gs_detector_*; these are the device ops such a
+ * graph is made of.  Parity for them is unpinned. */
+
+/* conv2d, NHWC fp32, weights [kh,kw,cin,cout] (TF layout), SAME-style explicit padding, + bias, optional ReLU. */
+gs_status gs_conv2d_nhwc(const float *in, int n, int h, int w, int cin, const float *weight, int kh, int kw,
+                         int cout, const float *bias_or_null, int stride, int pad, int relu, float *out,
+                         void *hip_stream);
+/* tf.image.crop_and_resize (the ROI pooling of TF-OD Faster R-CNN): boxes normalised [y1,x1,y2,x2],
+ * bilinear, extrapolation value 0.  feat NHWC fp32 -> out [n_boxes, crop, crop, c]. */
+gs_status gs_roialign(const float *feat, int n, int h, int w, int c, const float *boxes, const int *box_image,
+                      int n_boxes, int crop, float *out, void *hip_stream);
+/* Greedy IoU non-maximum suppression (tf.image.non_max_suppression): boxes [k,4] yxyx, scores [k];
+ * keep (device int32 [max_out]) receives indices in descending score order, *n_keep the count. */
+gs_status gs_nms(const float *boxes, const float *scores, int k, float iou_threshold, float score_threshold,
+                 int max_out, int *keep, int *n_keep, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLOMSEG_H */

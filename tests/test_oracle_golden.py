@@ -84,3 +84,15 @@ def test_ensemble_definition():
     ref = z["mask_0"]
     edge = np.unpackbits(z["edge_0"]).reshape(ref.shape).astype(bool)
     assert not ((mask != ref) & ~edge).any()
+
+
+def test_torch_port_matches_golden(sd1):
+    """the torch-operator port used as bench.py's cpu_baseline is pinned by the same vectors"""
+    import torch
+    from oracle import espnet_torch_port as port
+    z = load_golden("small_fold1.npz")
+    mean, std = FOLD_MEAN_STD[1]
+    sd = {k: torch.from_numpy(v) for k, v in sd1.items()}
+    for tag in "ac":
+        out = port.espnet_forward(port.preprocess(z["tile_" + tag][None], mean, std), sd)[0].numpy()
+        assert np.abs(out - z["logits_" + tag]).max() <= TOL
