@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Per-patch glomerular segmentation driver: same flags and outputs as the reference's
+module/espnet/test/VisualizeResults_iou.py (argparse :292-321, loop :84-241), with the batch-1
+eager loop replaced by batched HIP passes.
+
+    python -m glomeruli_segmentation_amd.segment --rgb_data_dir DIR --weights espnet_fold1.pth \
+        --mean 204.60071 170.19359 199.57469 --std 20.61257 42.92207 28.401505 --gpu_id 0 ...
+
+Additive flags: --batch (tiles per GPU pass), torchrun-style multi-process sharding is picked up
+from RANK/WORLD_SIZE (each rank takes a contiguous range of the sorted crop list).
+"""
+import glob
+import json
+import os
+import sys
+from argparse import ArgumentParser
+from collections import defaultdict
+
+import numpy as np
+
+from . import imageops
+from .shard import rank_range
+
+
+def build_parser():
+    p = ArgumentParser(description='Glomerular segmentation on the cropped images')
+    p.add_argument('--rgb_data_dir', default="./data", required=True)
+    p.add_argument('--label_data_dir', default=None)
+    p.add_argument('--img_extn', default="PNG")
+    p.add_argument('--inWidth', type=int, default=1024)
+    p.add_argument('--inHeight', type=int, default=512)
+    p.add_argument('--scaleIn', type=int, default=1)
+    p.add_argument('--modelType', type=int, default=1, help='1=ESPNet, 2=ESPNet-C')
+    p.add_argument('--savedir', default='./results')
+    p.add_argument('--gpu_id', default=-1, type=int)
+    p.add_argument('--decoder', action='store_true')
+    p.add_argument('--weights', required=True)
+    p.add_argument('--mean', required=True, nargs='*')
+    p.add_argument('--std', required=True, nargs='*')
+    p.add_argument('--p', default=2, type=int)
+    p.add_argument('--q', default=8, type=int)
+    p.add_argument('--cityFormat', action='store_true')
+    p.add_argument('--colored', action='store_true')
+    p.add_argument('--overlay', action='store_true')
+    p.add_argument('--classes', default=5, type=int)
+    p.add_argument('--batch', default=32, type=int, help='tiles per GPU pass (additive flag)')
+    return p
+
+
+def load_state_dict_file(path):
+    """torch .pth state_dict (the reference's format) or an .npz of the same keys."""
+    if path.endswith(".npz"):
+        z = np.load(path)
+        return {k: z[k] for k in z.files}
+    import torch
+    return torch.load(path, map_location="cpu")
+
+
+def confusion(pred, ref, classes):
+    """iouEval.fast_hist (module/common/IOUEval.py:19-21): rows = ground truth, cols = prediction."""
+    k = (ref >= 0) & (ref < classes)
+    return np.bincount(classes * ref[k].astype(int) + pred[k].astype(int), minlength=classes ** 2).reshape(classes, classes)
+
+
+def metric_right(hist):
+    """iouEval.getMetricRight (IOUEval.py:63-69), epsilon included."""
+    eps = 0.00000001
+    overall = np.diag(hist).sum() / (hist.sum() + eps)
+    per_acc = np.diag(hist) / (hist.sum(1) + eps)
+    per_iu = np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist) + eps)
+    return overall, per_acc, per_iu, np.nanmean(per_iu)
+
+
+def segment_images(engine, images, mean, std, width, height, batch):
+    """images: list of HxWx3 uint8 BGR crops of any size -> list of class maps at crop size.
+    Crops already at network size go down the fused uint8 path (normalisation in the first kernel);
+    others are normalised + resized on the host exactly in the reference's order (:107-116)."""
+    import torch
+    out = [None] * len(images)
+    native = [i for i, im in enumerate(images) if im.shape[:2] == (height, width)]
+    other = [i for i in range(len(images)) if images[i].shape[:2] != (height, width)]
+    for s in range(0, len(native), batch):
+        idx = native[s:s + batch]
+        tiles = torch.from_numpy(np.stack([images[i] for i in idx])).to(engine.device)
+        mask, _, _ = engine.segment(tiles, mean, std, want_hist=False)
+        mask = mask.cpu().numpy()
+        for j, i in enumerate(idx):
+            out[i] = mask[j]
+    for s in range(0, len(other), batch):
+        idx = other[s:s + batch]
+        x = np.stack([imageops.normalise_then_resize(images[i], mean, std, width, height) for i in idx])
+        logits = engine.forward_logits(torch.from_numpy(x).to(engine.device))
+        cls = logits.max(1)[1].byte().cpu().numpy()          # :128
+        for j, i in enumerate(idx):
+            h, w = images[i].shape[:2]
+            out[i] = imageops.resize_nearest(cls[j], w, h)    # :129
+    return out
+
+
+def evaluate(args, engine, rgb_list, label_list):
+    mean = [float(v) for v in args.mean]
+    std = [float(v) for v in args.std]
+    os.makedirs(args.savedir, exist_ok=True)
+    total_hist = None
+    dataset_d = defaultdict(lambda: defaultdict(int))
+    rows_pixel, rows_acc = [], []
+    for s in range(0, len(rgb_list), args.batch):
+        names = rgb_list[s:s + args.batch]
+        images = [imageops.imread_bgr(n) for n in names]
+        masks = segment_images(engine, images, mean, std, args.inWidth, args.inHeight, args.batch)
+        for img_name, label_name, img, cmap in zip(names, label_list[s:s + args.batch], images, masks):
+            patient = os.path.basename(os.path.dirname(img_name))
+            name = os.path.basename(img_name)
+            stem = name.rsplit(".", 1)[0]
+            odir = os.path.join(args.savedir, patient)
+            os.makedirs(odir, exist_ok=True)
+            if args.colored:
+                colour = imageops.colourise(cmap)
+                if args.overlay:
+                    imageops.imwrite_bgr(os.path.join(odir, stem + "_overlay.jpg"), imageops.add_weighted(img, 0.4, colour, 0.6))
+                    imageops.imwrite_bgr(os.path.join(odir, stem + "_org.png"), img)
+            counts = [int(np.count_nonzero(cmap == c)) for c in range(5)]                         # :151-155
+            rows_pixel.append("{},{},{},{},{},{},{}\n".format(patient, name.replace(args.img_extn, 'png'), *counts))
+            out_map = imageops.relabel_city(cmap) if args.cityFormat else cmap                     # :158-159
+            # The reference stores the ORIGINAL crop in the JSON's imageData (:179) although the WSI
+            # compositor reads it as a class map; this build writes the class map
+            # itself beside the JSON and records its name, and leaves polygon extraction (cv2
+            # findContours/approxPolyDP, boundary_extractor.py) to the "next" row of SURVEY 8f.
+            from PIL import Image
+            Image.fromarray(out_map).save(os.path.join(odir, stem + "_classmap.png"))
+            with open(os.path.join(odir, name.replace(args.img_extn, 'json')), 'w') as f:
+                json.dump({"shapes": [], "lineColor": [0, 0, 0, 255], "imagePath": name, "flags": {},
+                           "fillColor": [0, 0, 0, 255], "classMapPath": stem + "_classmap.png"}, f, indent=4)
+            if label_name is not None:
+                assert os.path.basename(img_name) == os.path.basename(label_name)
+                lab = np.asarray(Image.open(label_name))
+                assert lab.shape[:2] == img.shape[:2]
+                # the reference scores at network resolution (:195-203): nearest-resize both
+                lab_r = imageops.resize_nearest(lab, args.inWidth, args.inHeight)
+                pred_r = imageops.resize_nearest(cmap, args.inWidth, args.inHeight) if cmap.shape != lab_r.shape else cmap
+                hist = confusion(pred_r.ravel(), lab_r.ravel(), args.classes)
+                total_hist = hist if total_hist is None else total_hist + hist
+                uniq = np.unique(lab_r)
+                for v in uniq.tolist():
+                    dataset_d[patient][v] += 1
+                _, _, per_iu, _ = metric_right(hist)
+                union = hist.sum(1) + hist.sum(0) - np.diag(hist)
+                miou_each = np.nanmean(np.diag(hist)[uniq] / union[uniq])                           # :208-209
+                flags = [1 if (uniq == c).any() else 0 for c in range(1, 5)]
+                rows_acc.append("{}/{},{},{},{},{},{},{},{},{},{},{}\n".format(
+                    patient, name.replace(args.img_extn, 'png'), *flags, *per_iu[:5], miou_each))
+    rank = int(os.environ.get("RANK", "0"))
+    suffix = "" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else ".rank%d" % rank
+    with open(os.path.join(args.savedir, "summary_pixel.csv" + suffix), "w") as f:
+        f.write("patient_id, filename, background, glomerulus, crescent, sclerosis, mesangium\n")
+        f.writelines(rows_pixel)
+    with open(os.path.join(args.savedir, "summary_accuracy.csv" + suffix), "w") as f:
+        f.write("filename,glomerulus, crescent, sclerosis, mesangium, background iou,glomerulus iou,crescent iou,"
+                "sclerosis iou, mesangium iou,mIoU\n")
+        f.writelines(rows_acc)
+    with open(os.path.join(args.savedir, "summary_dataset.csv" + suffix), "w") as f:
+        f.write("patient_id, glomerulus, crescent, sclerosis, mesangium\n")
+        if total_hist is not None:
+            for patient, vals in dataset_d.items():
+                f.write(patient + "".join(",{}".format(vals[i]) for i in range(1, args.classes)) + "\n")
+    if total_hist is not None:
+        o, pa, pi, m = metric_right(total_hist)
+        with open(os.path.join(args.savedir, "overall_accuracy.txt" + suffix), "w") as f:
+            f.write("overall_acc:{}, per_class_acc:{}, per_class_iou:{}, mIOU:{}".format(o, pa, pi, m))
+    return total_hist
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    print(args.decoder)
+    if args.overlay:
+        args.colored = True
+    rgb_list = sorted(glob.glob(args.rgb_data_dir + "/*/*.PNG"))
+    if args.label_data_dir is not None:
+        label_list = sorted(glob.glob(args.label_data_dir + "/*/*.PNG"))
+        assert len(rgb_list) == len(label_list)
+    else:
+        label_list = [None] * len(rgb_list)
+    if args.modelType not in (1, 2):
+        print('Model not supported')
+        return 1
+    if not os.path.isfile(args.weights):
+        print('Pre-trained model file does not exist. Please check the --weights path')
+        return -1
+    if args.gpu_id < 0:
+        print("this build runs the ESPNet forward on a HIP device only: pass --gpu_id >= 0", file=sys.stderr)
+        return 2
+    import torch
+    from .engine import EspnetEngine
+    torch.cuda.set_device(args.gpu_id)
+    print('cuda:{}'.format(args.gpu_id))
+    lo, hi = rank_range(len(rgb_list), int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+    rgb_list, label_list = rgb_list[lo:hi], label_list[lo:hi]
+    print("num of image:{}".format(len(rgb_list)))
+    sd = load_state_dict_file(args.weights)
+    if args.modelType == 2:
+        raise SystemExit("modelType 2 (ESPNet-C + bilinear x8 upsampling) is served by Model.ESPNet_Encoder; "
+                         "the batch driver covers modelType 1")
+    engine = EspnetEngine(sd, classes=args.classes, p=args.p, q=args.q)
+    evaluate(args, engine, rgb_list, label_list)
+    engine.close()
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

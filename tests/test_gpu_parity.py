@@ -1,5 +1,7 @@
 """HIP path (through the C ABI) vs golden vectors generated from the reference and vs the CPU
 oracle on the same seeded inputs.  Needs a real MI355X: run with `-m gpu`."""
+import os
+
 import numpy as np
 import pytest
 
@@ -188,3 +190,131 @@ def test_error_paths(torch_mod, engine1):
     from glomeruli_segmentation_amd.engine import EspnetEngine
     with pytest.raises(_lib.GlomsegError):
         EspnetEngine(sd)
+
+
+def test_model_shim_forward_is_drop_in(torch_mod, sd1):
+    """the reference's call sequence (VisualizeResults_iou.py:274-284,123) on the drop-in module"""
+    torch = torch_mod
+    import glomeruli_segmentation_amd.Model as Net
+    z = load_golden("stages_fold1.npz")
+    model = Net.ESPNet(5, 2, 8)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd1.items()})
+    model = model.to("cuda:0")
+    with pytest.raises(RuntimeError):
+        model(torch.from_numpy(z["input"][None]).to("cuda:0"))       # still in train mode
+    model.eval()
+    img_out = model(torch.from_numpy(z["input"][None]).to("cuda:0"))
+    assert img_out.shape == (1, 5, 64, 128)
+    assert np.abs(img_out[0].cpu().numpy() - z["logits"]).max() <= LOGIT_TOL
+    class_map = img_out[0].max(0)[1].byte().cpu().data.numpy()          # :128
+    assert (class_map == z["logits"].argmax(0)).mean() >= 0.9999
+    # new weights must invalidate the packed copy
+    sd2 = load_weights(2)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+    out2 = model(torch.from_numpy(z["input"][None]).to("cuda:0"))
+    assert np.abs(out2[0].cpu().numpy() - z["logits"]).max() > 1e-2
+
+
+def test_driver_end_to_end(torch_mod, tmp_path):
+    """CLI with the reference's flags over a directory of PNG crops (one network-sized, one not)"""
+    from PIL import Image
+    from conftest import GOLDEN
+    from glomeruli_segmentation_amd import segment
+    from glomeruli_segmentation_amd.synth import synth_tile
+    d = tmp_path / "org_image" / "PAS-001"
+    d.mkdir(parents=True)
+    a = synth_tile(0)
+    Image.fromarray(a[:, :, ::-1]).save(d / "xmin0_ymin0_xmax128_ymax64.PNG")
+    b = synth_tile(5, 300, 420, blobs=5)
+    Image.fromarray(b[:, :, ::-1]).save(d / "xmin9_ymin9_xmax61_ymax46.PNG")
+    out = tmp_path / "results"
+    rc = segment.main(["--rgb_data_dir", str(tmp_path / "org_image"), "--savedir", str(out), "--weights",
+                       os.path.join(GOLDEN, "weights_fold1.npz"), "--gpu_id", "0", "--mean", "204.60071", "170.19359",
+                       "199.57469", "--std", "20.61257", "42.92207", "28.401505", "--colored", "--overlay", "--batch", "4"])
+    assert rc == 0
+    rows = open(out / "summary_pixel.csv").read().strip().splitlines()
+    assert len(rows) == 3
+    z = load_golden("masks_fold1.npz")
+    got = [int(v) for v in rows[1].split(",")[2:]]
+    assert np.abs(np.array(got) - z["hist_0"]).sum() <= 16              # same counts as the reference's mask
+    cm = np.asarray(Image.open(out / "PAS-001" / "xmin0_ymin0_xmax128_ymax64_classmap.png"))
+    assert (cm != z["mask_0"]).sum() <= 8
+    cm2 = np.asarray(Image.open(out / "PAS-001" / "xmin9_ymin9_xmax61_ymax46_classmap.png"))
+    assert cm2.shape == (300, 420)
+    assert (out / "PAS-001" / "xmin0_ymin0_xmax128_ymax64_overlay.jpg").exists()
+
+
+def test_detector_primitives_self_consistency(torch_mod):
+    """conv2d NHWC / crop_and_resize / NMS against torch CPU ops and a numpy restatement of the
+    published TF semantics.  NOT reference parity (the detector graph is external)."""
+    import ctypes
+    torch = torch_mod
+    from glomeruli_segmentation_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    # conv2d
+    x = torch.randn(2, 19, 23, 7, generator=g)
+    w = torch.randn(3, 3, 7, 37, generator=g) * 0.2
+    bias = torch.randn(37, generator=g)
+    ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), bias, 2, 1)).permute(0, 2, 3, 1)
+    xd, wd, bd = x.cuda(), w.cuda(), bias.cuda()
+    out = torch.empty(ref.shape, device="cuda")
+    _lib.check(lib.gs_conv2d_nhwc(xd.data_ptr(), 2, 19, 23, 7, wd.data_ptr(), 3, 3, 37, bd.data_ptr(), 2, 1, 1,
+                                  out.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max() <= 1e-4
+    # crop_and_resize
+    feat = torch.randn(2, 11, 13, 5, generator=g)
+    boxes = torch.tensor([[0.1, 0.2, 0.7, 0.9], [0.0, 0.0, 1.0, 1.0], [-0.2, 0.3, 0.5, 1.2]])
+    bimg = torch.tensor([0, 1, 1], dtype=torch.int32)
+    crop = 4
+    got = torch.empty((3, crop, crop, 5), device="cuda")
+    fd, bxd, bid = feat.cuda(), boxes.cuda(), bimg.cuda()      # keep the device copies alive across the call
+    _lib.check(lib.gs_roialign(fd.data_ptr(), 2, 11, 13, 5, bxd.data_ptr(), bid.data_ptr(), 3, crop, got.data_ptr(), None))
+    torch.cuda.synchronize()
+    f = feat.numpy()
+    exp = np.zeros((3, crop, crop, 5), np.float32)
+    for b in range(3):
+        y1, x1, y2, x2 = boxes[b].tolist()
+        for i in range(crop):
+            for j in range(crop):
+                iy = y1 * 10 + i * (y2 - y1) * 10 / (crop - 1)
+                ix = x1 * 12 + j * (x2 - x1) * 12 / (crop - 1)
+                if iy < 0 or iy > 10 or ix < 0 or ix > 12:
+                    continue
+                t, l = int(np.floor(iy)), int(np.floor(ix))
+                bo, r = int(np.ceil(iy)), int(np.ceil(ix))
+                fy, fx = iy - t, ix - l
+                im = f[int(bimg[b])]
+                top = im[t, l] + (im[t, r] - im[t, l]) * fx
+                bot = im[bo, l] + (im[bo, r] - im[bo, l]) * fx
+                exp[b, i, j] = top + (bot - top) * fy
+    assert np.abs(got.cpu().numpy() - exp).max() <= 1e-4
+    # NMS
+    k = 300
+    c = torch.rand(k, 2, generator=g) * 0.8
+    s = torch.rand(k, 2, generator=g) * 0.2 + 0.02
+    bx = torch.cat([c, c + s], 1)
+    sc = torch.rand(k, generator=g)
+    keep = torch.full((k,), -1, dtype=torch.int32, device="cuda")
+    nk = torch.zeros(1, dtype=torch.int32, device="cuda")
+    bxg, scg = bx.cuda(), sc.cuda()
+    _lib.check(lib.gs_nms(bxg.data_ptr(), scg.data_ptr(), k, ctypes.c_float(0.3), ctypes.c_float(0.2), 100,
+                          keep.data_ptr(), nk.data_ptr(), None))
+    torch.cuda.synchronize()
+    order = sorted([i for i in range(k) if sc[i] > 0.2], key=lambda i: (-float(sc[i]), i))
+    sel = []
+    bn = bx.numpy()
+
+    def iou(a, b):
+        ih = max(min(a[2], b[2]) - max(a[0], b[0]), 0)
+        iw = max(min(a[3], b[3]) - max(a[1], b[1]), 0)
+        inter = ih * iw
+        return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter)
+    for i in order:
+        if len(sel) >= 100:
+            break
+        if all(iou(bn[i], bn[j]) <= 0.3 for j in sel):
+            sel.append(i)
+    n = int(nk.item())
+    assert keep[:n].cpu().tolist() == sel

@@ -1,0 +1,174 @@
+"""CPU tests of the host side: C-ABI exports, drop-in Model shim, sharding (gloo, 2 ranks),
+driver helpers.  No GPU compute is called."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_golden, load_weights
+
+
+def test_cabi_exports_every_declared_symbol():
+    from glomeruli_segmentation_amd import _lib
+    from glomeruli_segmentation_amd.build import build_lib
+    build_lib()
+    header = open(os.path.join(REPO, "include", "glomseg.h")).read()
+    declared = set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    lib = _lib.load()                       # resolves every prototype or raises
+    assert lib.gs_abi_version() == _lib.ABI_VERSION
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (gs_[a-z0-9_]+)", out))
+    assert declared <= exported
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from glomeruli_segmentation_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        _lib.load()
+
+
+def test_pack_state_dict_layout(sd1):
+    from glomeruli_segmentation_amd.engine import pack_state_dict
+    blob, table = pack_state_dict(sd1)
+    assert len(table) == sum(1 for v in sd1.values() if v.dtype.kind == "f")     # int64 counters skipped
+    names = {t.name.decode(): t for t in table}
+    t = names["encoder.level3.7.d16.conv.weight"]
+    assert list(t.shape) == [25, 25, 3, 3] and t.ndim == 4
+    assert np.array_equal(blob[t.offset:t.offset + 25 * 25 * 9], sd1["encoder.level3.7.d16.conv.weight"].ravel())
+    assert blob.size == sum(v.size for v in sd1.values() if v.dtype.kind == "f")
+
+
+def test_model_shim_state_dict_is_drop_in(sd1):
+    """same parameter tree as the reference: every key of espnet_fold1.pth loads, none is left over"""
+    import torch
+    import glomeruli_segmentation_amd.Model as Net
+    net = Net.ESPNet(5, 2, 8)
+    msg = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd1.items()})
+    assert not msg.missing_keys and not msg.unexpected_keys
+    assert set(net.state_dict().keys()) == set(sd1.keys()) and len(sd1) == 205
+    assert isinstance(net.modules, list) and len(net.modules) == 11          # the reference's shadowing list
+    enc = Net.ESPNet_Encoder(5, 2, 8)
+    enc.load_state_dict({k[8:]: torch.from_numpy(v) for k, v in sd1.items() if k.startswith("encoder.")})
+    assert Net.ESPNet().encoder.level3.__len__() == 3 and Net.ESPNet_Encoder().level2.__len__() == 5   # ctor defaults
+
+
+def test_model_shim_cpu_is_refused_unless_opted_in(sd1, monkeypatch):
+    import torch
+    import glomeruli_segmentation_amd.Model as Net
+    net = Net.ESPNet(5, 2, 8)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd1.items()})
+    net.eval()
+    z = load_golden("stages_fold1.npz")
+    x = torch.from_numpy(z["input"][None])
+    monkeypatch.delenv("GLOMSEG_ALLOW_TORCH_CPU", raising=False)
+    with pytest.raises(RuntimeError):
+        net(x)
+    monkeypatch.setenv("GLOMSEG_ALLOW_TORCH_CPU", "1")
+    with torch.no_grad():
+        out = net(x)[0].numpy()
+    assert np.abs(out - z["logits"]).max() <= 1e-4      # the shim's torch graph is the reference's graph
+
+
+def test_rank_range_partitions_exactly():
+    from glomeruli_segmentation_amd.shard import plan_grid, rank_range
+    for total in (0, 1, 7, 36, 1369):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = rank_range(total, r, world)
+                cover.extend(range(lo, hi))
+            assert cover == list(range(total))
+    grid = plan_grid(1000, 2300, 512, 1024)
+    assert grid[0] == (0, 0) and grid[-1] == (488, 1276) and len(grid) == 2 * 3
+    with pytest.raises(ValueError):
+        rank_range(4, 2, 2)
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["GS_REPO"])
+from glomeruli_segmentation_amd.shard import segment_sharded
+from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+from oracle import espnet_oracle as orc
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+z = np.load(os.path.join(os.environ["GS_REPO"], "tests", "golden", "weights_fold1.npz"))
+sd = {k: z[k] for k in z.files}
+mean, std = FOLD_MEAN_STD[1]
+TOTAL = 5
+
+def load(lo, hi):
+    return np.stack([synth_tile(100 + i, 32, 64, blobs=2) for i in range(lo, hi)])
+
+def compute(tiles):          # the checker stands in for the GPU pass in this CPU test
+    res = [orc.segment_tile(t, sd, mean, std) for t in tiles]
+    return np.stack([r[1] for r in res]), np.stack([r[2] for r in res])
+
+masks, counts = segment_sharded(compute, load, TOTAL, rank, world, dist=dist, batch=2)
+if rank == 0:
+    np.savez(os.environ["GS_OUT"], masks=masks, counts=counts)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_sharding_equals_single_process(tmp_path):
+    """world_size-2 gloo run gives byte-identical masks and counts to one process"""
+    from glomeruli_segmentation_amd.shard import segment_sharded
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    from oracle import espnet_oracle as orc
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    out = tmp_path / "out.npz"
+    env = dict(os.environ, GS_REPO=REPO, GS_OUT=str(out), MASTER_ADDR="127.0.0.1", MASTER_PORT="29617",
+               WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = np.load(out)
+    sd = load_weights(1)
+    mean, std = FOLD_MEAN_STD[1]
+
+    def compute(tiles):
+        res = [orc.segment_tile(t, sd, mean, std) for t in tiles]
+        return np.stack([r[1] for r in res]), np.stack([r[2] for r in res])
+
+    masks, counts = segment_sharded(compute, lambda lo, hi: np.stack([synth_tile(100 + i, 32, 64, blobs=2) for i in range(lo, hi)]),
+                                    5, 0, 1)
+    assert np.array_equal(got["masks"], masks) and np.array_equal(got["counts"], counts)
+    assert counts.sum() == 5 * 32 * 64
+
+
+def test_image_helpers():
+    from glomeruli_segmentation_amd import imageops
+    rng = np.random.default_rng(0)
+    img = rng.random((6, 10, 3)).astype(np.float32)
+    assert np.array_equal(imageops.resize_linear_f32(img, 10, 6), img)             # identity at equal size
+    up = imageops.resize_linear_f32(img, 20, 12)
+    assert up.shape == (12, 20, 3) and np.allclose(up[0, 0], img[0, 0]) and np.allclose(up[-1, -1], img[-1, -1])
+    cm = rng.integers(0, 5, (6, 10)).astype(np.uint8)
+    nn = imageops.resize_nearest(cm, 20, 12)
+    assert (nn[::2, ::2] == cm).all() and (nn[1::2, 1::2] == cm).all()
+    city = imageops.relabel_city(np.arange(5, dtype=np.uint8))
+    assert city.tolist() == [7, 8, 11, 12, 13]                                     # VisualizeResults_iou.py:54-81
+    a = np.full((2, 2, 3), 100, np.uint8)
+    b = np.full((2, 2, 3), 201, np.uint8)
+    assert imageops.add_weighted(a, 0.4, b, 0.6)[0, 0, 0] == 161                   # round(40 + 120.6)
+
+
+def test_driver_flags_match_reference():
+    from glomeruli_segmentation_amd.segment import build_parser
+    a = build_parser().parse_args(["--rgb_data_dir", "d", "--weights", "w", "--mean", "1", "2", "3", "--std", "1", "1", "1"])
+    assert (a.inWidth, a.inHeight, a.modelType, a.p, a.q, a.classes, a.gpu_id, a.img_extn, a.savedir, a.scaleIn) == \
+        (1024, 512, 1, 2, 8, 5, -1, "PNG", "./results", 1)
+    assert not (a.cityFormat or a.colored or a.overlay or a.decoder)
