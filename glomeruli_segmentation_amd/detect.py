@@ -1,0 +1,149 @@
+"""Host side of the sliding-window glomerulus detector: window geometry, level choice, box
+post-processing and the detections CSV -- the call surface of the reference's
+module/faster-rcnn/detect_glomus_test.py around its ``sess.run`` (:350-352).
+
+The detector NETWORK is an external TensorFlow-1.12 frozen graph that is not part of the reference
+(:419-427; download in example/README.md:22), so here it is a plug-in: any callable with the
+``detect_box`` tensor contract
+
+    detector(uint8 RGB [1,H,W,3]) -> (boxes [1,K,4] normalised [ymin,xmin,ymax,xmax],
+                                      scores [1,K] descending, classes [1,K], num [1])
+
+(:443-450).  Everything in this file is pinned by known-answer tests written from the reference's
+formulas; parity for a network behind the plug-in is unpinned.
+"""
+import datetime
+import math
+from argparse import ArgumentParser
+from dataclasses import dataclass
+
+import numpy as np
+
+from .shard import rank_range
+
+DEFAULT_WINDOW_UM = 500      # detect_glomus_test.py:52-54
+DEFAULT_OVERLAP = 0.5
+
+
+def pick_level(objective_power, level_downsamples):
+    """First pyramid level whose magnification is <= 5x; level 3 / downsample 8 when none is
+    (detect_glomus_test.py:255-261)."""
+    for level, ds in enumerate(level_downsamples):
+        if objective_power / ds <= 5.0:
+            return level, float(ds)
+    return 3, 8.0
+
+
+@dataclass
+class WindowPlan:
+    window_x_org: float      # window edge in level-0 pixels
+    window_y_org: float
+    x_split_times: int
+    y_split_times: int
+    window_x: int            # window edge in pixels of the level that is read
+    window_y: int
+    step_x: int              # window stride
+    step_y: int
+    downsample: float
+
+    def origins(self):
+        """Row-major (i, j, x_start, y_start) of every window (:270-273)."""
+        return [(i, j, self.step_x * i, self.step_y * j)
+                for j in range(self.y_split_times) for i in range(self.x_split_times)]
+
+
+def plan_windows(width, height, mpp_x, mpp_y, downsample, window_um=None, overlap=None, from_image=False):
+    """calc_window_size (:286-304) + the stride of scan_region (:266-268; level-0 pixels) or of
+    scan_region_from_image (:218-219; pixels of the down-sampled PNG) when ``from_image``."""
+    if window_um is None or window_um == '':
+        window_um, overlap = DEFAULT_WINDOW_UM, DEFAULT_OVERLAP
+    wx_org = float(window_um) / mpp_x
+    wy_org = float(window_um) / mpp_y
+    xs = int(math.ceil(width / wx_org / (1.0 - overlap)))
+    ys = int(math.ceil(height / wy_org / (1.0 - overlap)))
+    wx = int(math.ceil(wx_org / downsample))
+    wy = int(math.ceil(wy_org / downsample))
+    if from_image:
+        sx, sy = int(wx * (1.0 - overlap)), int(wy * (1.0 - overlap))
+    else:
+        sx, sy = int(wx_org * (1.0 - overlap)), int(wy_org * (1.0 - overlap))
+    return WindowPlan(wx_org, wy_org, xs, ys, wx, wy, sx, sy, float(downsample))
+
+
+def boxes_from_detector(boxes, scores, window_x, window_y, thresh=0.5):
+    """Threshold + denormalise (:355-368).  Quirk kept: the first len(score >= thresh) boxes are
+    taken by position, which equals selection by index only because detector outputs are sorted by
+    descending score."""
+    boxes = np.squeeze(np.asarray(boxes))
+    score = np.squeeze(np.asarray(scores))
+    boxes = boxes.reshape(-1, 4)
+    score = score.reshape(-1)
+    n = int(np.count_nonzero(score >= thresh))
+    out = []
+    for i in range(n):
+        ymin, xmin, ymax, xmax = boxes[i]
+        out.append([int(window_x * xmin), int(window_y * ymin), int(window_x * xmax), int(window_y * ymax), score[i]])
+    return out
+
+
+def csv_rows(bs, x_start, y_start, downsample, site_name, specimen_id, file_name, now=None):
+    """Window -> level-0 coordinates and the detections CSV row format (:306-326)."""
+    rows = []
+    stamp = (now or datetime.datetime.today()).strftime('%Y-%m-%dT%H:%M:%S')
+    for b in bs:
+        if b[4] > 0:
+            rows.append('"' + site_name + '","' + specimen_id + '","' + file_name + '",new,' + stamp + ','
+                        + str(x_start + (b[0] * downsample)) + ',' + str(y_start + (b[1] * downsample)) + ','
+                        + str(x_start + (b[2] * downsample)) + ',' + str(y_start + (b[3] * downsample)) + ','
+                        + str(b[4]) + '\n')
+    return rows
+
+
+def scan_slide(read_region, detector, plan, conf_threshold, site_name, specimen_id, file_name, rank=0, world=1,
+               from_image=False, now=None):
+    """The HOT LOOP of scan_region (:270-284) for this rank's contiguous window range.
+    read_region(x_start, y_start, window_x, window_y) -> uint8 RGB [window_y, window_x, 3]."""
+    wins = plan.origins()
+    lo, hi = rank_range(len(wins), rank, world)
+    rows = []
+    for i, j, xs, ys in wins[lo:hi]:
+        im = np.asarray(read_region(xs, ys, plan.window_x, plan.window_y))
+        if im.shape[-1] == 4:
+            im = im[:, :, :3]                        # drop alpha (:277-278)
+        boxes, scores, classes, num = detector(im[None])
+        bs = boxes_from_detector(boxes, scores, plan.window_x, plan.window_y, conf_threshold)
+        x0, y0 = (xs * plan.downsample, ys * plan.downsample) if from_image else (xs, ys)     # :234 vs :283
+        rows.extend(csv_rows(bs, x0, y0, plan.downsample, site_name, specimen_id, file_name, now))
+    return rows
+
+
+def parse_target_line(line):
+    """One line of the target list: "id/file[,w,h,power,ds,mppx,mppy]"; short lines zero the slide
+    metadata silently, as the reference does (:112-129).  Returns None for '#' comment lines."""
+    parts = line.strip().split(',')
+    meta = dict(width=0, height=0, objective_power=0.0, downsample=0.0, mpp_x=0.0, mpp_y=0.0)
+    if len(parts) >= 7:
+        meta = dict(width=int(parts[1]), height=int(parts[2]), objective_power=float(parts[3]),
+                    downsample=float(parts[4]), mpp_x=float(parts[5]), mpp_y=float(parts[6]))
+    ids = parts[0].split('/')
+    if ids[0].startswith('#'):
+        return None
+    meta["specimen_id"] = ids[0]
+    meta["file_name"] = ids[1] if len(ids) > 1 else ""
+    return meta
+
+
+def build_parser():
+    """argparse surface of detect_glomus_test.py:385-405."""
+    p = ArgumentParser(description='Load RoI')
+    p.add_argument('--model', dest='model', type=str)
+    p.add_argument('--target_list', dest='target_list', type=str)
+    p.add_argument('--data_dir', dest='data_dir', type=str)
+    p.add_argument('--staining', dest='data_category', type=str, default='OPT_PAM')
+    p.add_argument('--output_dir', dest='output_dir', type=str, default='./output')
+    p.add_argument('--output_file_ext', dest='output_file_ext', type=str, default='_GlomusList')
+    p.add_argument('--window_size', dest='window_size', type=int)
+    p.add_argument('--overlap_ratio', dest='overlap_ratio', type=float)
+    p.add_argument('--conf_threshold', dest='conf_threshold', type=float, default=0.6)
+    p.add_argument('--model_name', dest='model_name', default="frozen_inference_graph.pb", type=str)
+    return p

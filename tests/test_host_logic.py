@@ -172,3 +172,65 @@ def test_driver_flags_match_reference():
     assert (a.inWidth, a.inHeight, a.modelType, a.p, a.q, a.classes, a.gpu_id, a.img_extn, a.savedir, a.scaleIn) == \
         (1024, 512, 1, 2, 8, 5, -1, "PNG", "./results", 1)
     assert not (a.cityFormat or a.colored or a.overlay or a.decoder)
+
+
+def test_detector_window_geometry_known_answers():
+    """written from detect_glomus_test.py:286-304,255-261 with the example slide of SURVEY 8c:
+    53248 x 23040 px (6656 x 2880 at ds 8), mpp 0.2277, --window_size 2000 --overlap_ratio 0.1"""
+    import math
+    from glomeruli_segmentation_amd import detect
+    assert detect.pick_level(40, [1.0, 2.0, 4.0, 8.0, 16.0]) == (3, 8.0)
+    assert detect.pick_level(20, [1.0, 2.0, 4.0]) == (2, 4.0)
+    assert detect.pick_level(40, [1.0, 2.0]) == (3, 8.0)                    # fallback :255-256
+    p = detect.plan_windows(53248, 23040, 0.2277, 0.2277, 8.0, 2000, 0.1)
+    assert math.isclose(p.window_x_org, 2000 / 0.2277)
+    assert (p.x_split_times, p.y_split_times, p.window_x, p.window_y) == (7, 3, 1098, 1098)
+    assert (p.step_x, p.step_y) == (7905, 7905)                              # int(8783.48 * 0.9), level-0 px
+    assert p.origins()[8] == (1, 1, 7905, 7905) and len(p.origins()) == 21
+    d = detect.plan_windows(40000, 40000, 0.2277, 0.2277, 8.0, None, None)   # defaults 500 um / 0.5
+    assert (d.x_split_times, d.window_x, d.step_x) == (37, 275, 1097)
+    pi = detect.plan_windows(6656, 2880, 0.2277, 0.2277, 8.0, 2000, 0.1, from_image=True)
+    assert pi.step_x == int(1098 * 0.9)                                      # :218 stride in PNG pixels
+
+
+def test_detector_box_postprocessing_and_csv():
+    import datetime
+    from glomeruli_segmentation_amd import detect
+    boxes = np.array([[[0.1, 0.2, 0.5, 0.6], [0.0, 0.0, 1.0, 1.0], [0.3, 0.3, 0.4, 0.4]]], dtype=np.float32)
+    scores = np.array([[0.9, 0.61, 0.2]], dtype=np.float32)
+    bs = detect.boxes_from_detector(boxes, scores, 1098, 1000, thresh=0.6)
+    assert [b[:4] for b in bs] == [[int(1098 * np.float32(0.2)), 100, int(1098 * np.float32(0.6)), 500], [0, 0, 1098, 1000]]
+    now = datetime.datetime(2020, 1, 2, 3, 4, 5)
+    rows = detect.csv_rows(bs, 7905, 0, 8.0, "site", "PAS-001", "PAS-001.ndpi", now)
+    x1 = 7905 + bs[0][0] * 8.0
+    assert rows[0] == '"site","PAS-001","PAS-001.ndpi",new,2020-01-02T03:04:05,%s,800.0,%s,4000.0,%s\n' % (
+        str(x1), str(7905 + bs[0][2] * 8.0), str(bs[0][4]))
+    assert detect.boxes_from_detector(boxes, np.zeros((1, 3)), 10, 10, 0.5) == []
+    assert detect.parse_target_line("#PAS-001/PAS-001") is None
+    m = detect.parse_target_line("PAS-001/PAS-001,53248,23040,40,8,0.2277,0.2277\n")
+    assert (m["width"], m["mpp_x"], m["specimen_id"], m["file_name"]) == (53248, 0.2277, "PAS-001", "PAS-001")
+    assert detect.parse_target_line("PAS-001/PAS-001")["width"] == 0       # short line zeroes metadata (:115-122)
+
+
+def test_detector_scan_shards_by_window_range():
+    import datetime
+    from glomeruli_segmentation_amd import detect
+    plan = detect.plan_windows(8000, 4000, 0.25, 0.25, 8.0, 500, 0.5)
+    calls = []
+
+    def read_region(x, y, w, h):
+        calls.append((x, y))
+        return np.zeros((h, w, 4), dtype=np.uint8)
+
+    def detector(im):
+        assert im.shape == (1, plan.window_y, plan.window_x, 3) and im.dtype == np.uint8
+        return np.array([[[0.0, 0.0, 0.5, 0.5]]]), np.array([[0.7]]), np.array([[1]]), np.array([1])
+
+    now = datetime.datetime(2020, 1, 1)
+    whole = detect.scan_slide(read_region, detector, plan, 0.6, "s", "p", "f", now=now)
+    parts = []
+    for r in range(3):
+        parts += detect.scan_slide(read_region, detector, plan, 0.6, "s", "p", "f", rank=r, world=3, now=now)
+    assert parts == whole and len(whole) == plan.x_split_times * plan.y_split_times
+    a = detect.build_parser().parse_args([])
+    assert (a.data_category, a.conf_threshold, a.model_name, a.output_file_ext) == ("OPT_PAM", 0.6, "frozen_inference_graph.pb", "_GlomusList")
