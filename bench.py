@@ -126,10 +126,12 @@ def main():
 
     def step():
         eng.segment(tiles, mean, std, out_mask=mask, out_hist=hist)
+        totals.add_(hist.sum(0))
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):   # also loads torch's own reduce/add code objects once
         step()
     torch.cuda.synchronize()
+    totals.zero_()
 
     def timed(steps):
         if dist is not None:
@@ -138,7 +140,6 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
-            totals.add_(hist.sum(0))
         if dist is not None:
             dist.all_reduce(totals)        # the one exchange: slide-level per-class pixel totals
         torch.cuda.synchronize()

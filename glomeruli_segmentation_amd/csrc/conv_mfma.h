@@ -65,6 +65,7 @@ struct ConvArgs {
     float *out;
     long long out_sn;
     int out_sc, out_pitch, out_off;
+    unsigned out_img_bytes, res_img_bytes;
     const float *res;
     long long res_sn;
     int res_sc, res_pitch, res_off;
@@ -84,6 +85,9 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     constexpr int COUT = NOUT1 + (NDIL - 1) * NOUT;
     constexpr int TYN = TAPS == 9 ? 3 : 1;
     constexpr int TXN = TAPS == 9 ? 3 : 1;
+    constexpr int TXG = TXN / TXU, SG = NSTEP / UNR;
+    constexpr int CPD = TYN * TXG * SG;   // chunks per dilation
+    constexpr int NCHUNK = NDIL * CPD;
     static_assert(CINP % KL == 0 && NSTEP % UNR == 0, "k-steps must tile");
     static_assert(TAPS == 1 || TAPS == 9, "1x1 or 3x3");
     static_assert(TXN % TXU == 0, "tap unroll");
@@ -101,6 +105,9 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     const int px = lane % MT, kq = lane / MT;
     const int voff = (kq * a.in_sc + px * STRIDE) * 4;
     const int lbase = kq * NROW + (px < NROW ? px : NROW - 1);
+    constexpr int KSTR = MT == 32 ? 4 : 4;   // accumulator rows of k-group kq sit KSTR*kq above those of group 0
+    const int vout = (kq * KSTR * a.out_sc + px) * 4;
+    const int vres = RES ? (kq * KSTR * a.res_sc + px) * 4 : 0;
 
     // Each wave takes a contiguous range of tasks; workgroups that share an XCD (equal
     // blockIdx % 8 under round-robin dispatch: speed only) take neighbouring ranges, so one XCD's
@@ -123,84 +130,120 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.in + (long long)n * a.in_sn), 0, a.in_img_bytes, 0x00020000);
         const int sbase = (a.in_off + y * STRIDE * a.in_pitch + x0 * STRIDE) * 4;
+        const __amdgpu_buffer_rsrc_t rout =
+            __builtin_amdgcn_make_buffer_rsrc(a.out + (long long)n * a.out_sn, 0, a.out_img_bytes, 0x00020000);
+        const int sout = (a.out_off + y * a.out_pitch + x0) * 4;
+        const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(RES ? a.res + (long long)n * a.res_sn : a.in), 0, RES ? a.res_img_bytes : 0u, 0x00020000);
+        const int sres = RES ? (a.res_off + y * a.res_pitch + x0) * 4 : 0;
 
         typename M::acc_t acc[P];
 
-        for (int di = 0; di < NDIL; ++di) {
+        // The k-loop is a flat sequence of NCHUNK chunks, chunk = (dilation, tap row, TXU taps, UNR
+        // k-steps), software-pipelined by hand with ONE register set used as a ring: right after the
+        // MFMAs of k-step u of chunk c have consumed their operands, the same registers are refilled
+        // with k-step u of chunk c+1.  Every load therefore has a whole chunk of MFMA work (thousands
+        // of cycles) to land, at no extra register cost.  (The first version waited on loads it had
+        // just issued: SQ_WAIT_ANY 57 % of wave cycles, MFMA pipe 42 % busy.)
+        struct ChunkAddr {
+            int soff[TXU];
+            const float *wl[TXU];
+        };
+        auto locate = [&](int c) {
+            ChunkAddr ca;
+            const int di = c / CPD;
+            int r = c - di * CPD;
+            const int ty = r / (TXG * SG);
+            r -= ty * (TXG * SG);
+            const int tg = r / SG;
+            const int s0 = (r - tg * SG) * UNR;
+            const int tx0 = tg * TXU;
             const int d = 1 << di;
-            if (di < 2) {
+#pragma unroll
+            for (int j = 0; j < TXU; ++j) {
+                const int tap = TAPS == 9 ? ty * 3 + tx0 + j : 0;
+                const int toff = TAPS == 9 ? ((ty - 1) * a.in_pitch + (tx0 + j - 1)) * d : 0;
+                ca.soff[j] = sbase + toff * 4 + s0 * KL * a.in_sc * 4;
+                ca.wl[j] = lds + (di * TAPS + tap) * (CINP * NROW) + s0 * KL * NROW + lbase;
+            }
+            return ca;
+        };
+        float aq[TXU][UNR], bq[TXU][UNR][P];
+        auto fetch = [&](const ChunkAddr &ca, int j, int u) {
+            aq[j][u] = ca.wl[j][u * KL * NROW];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                bq[j][u][p] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + p * MT * STRIDE * 4,
+                                                                ca.soff[j] + u * KL * a.in_sc * 4, 0));
+        };
+        auto compute = [&](int c) {
+            if (c % CPD == 0 && c < 2 * CPD) {   // d1 and d2 start fresh; d4, d8, d16 keep adding (HFF)
 #pragma unroll
                 for (int p = 0; p < P; ++p)
                     acc[p] = (typename M::acc_t)(0.0f);
             }
-            for (int ty = 0; ty < TYN; ++ty) {
-                for (int tx0 = 0; tx0 < TXN; tx0 += TXU) {
-                    for (int s0 = 0; s0 < NSTEP; s0 += UNR) {
-                        float aq[TXU][UNR];
-                        float bq[TXU][UNR][P];
+            const ChunkAddr nx = locate(c + 1 < NCHUNK ? c + 1 : c);   // the last chunk refetches itself (unused)
 #pragma unroll
-                        for (int j = 0; j < TXU; ++j) {
-                            const int tap = TAPS == 9 ? ty * 3 + tx0 + j : 0;
-                            const int toff = TAPS == 9 ? ((ty - 1) * a.in_pitch + (tx0 + j - 1)) * d : 0;
-                            const int soff = sbase + toff * 4 + s0 * KL * a.in_sc * 4;
-                            const float *wl = lds + (di * TAPS + tap) * (CINP * NROW) + s0 * KL * NROW + lbase;
+            for (int j = 0; j < TXU; ++j)
 #pragma unroll
-                            for (int u = 0; u < UNR; ++u) {
-                                aq[j][u] = wl[u * KL * NROW];
+                for (int u = 0; u < UNR; ++u) {
 #pragma unroll
-                                for (int p = 0; p < P; ++p)
-                                    bq[j][u][p] = __builtin_bit_cast(
-                                        float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                   rsrc, voff + p * MT * STRIDE * 4, soff + u * KL * a.in_sc * 4, 0));
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < TXU; ++j)
-#pragma unroll
-                            for (int u = 0; u < UNR; ++u)
-#pragma unroll
-                                for (int p = 0; p < P; ++p)
-                                    acc[p] = M::run(aq[j][u], bq[j][u][p], acc[p]);
-                    }
+                    for (int p = 0; p < P; ++p)
+                        acc[p] = M::run(aq[j][u], bq[j][u][p], acc[p]);
+                    fetch(nx, j, u);
+                    // pin the ring order: left alone, hipcc sinks the refill loads to the end of the
+                    // chunk, which shrinks the prefetch distance from a chunk to a few k-steps
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
-
-            // write this branch's concat slot (the accumulator keeps running for the fusion adds)
+            if ((c + 1) % CPD != 0)
+                return;
+            // last chunk of a dilation: write this branch's concat slot (the accumulator keeps
+            // running for the fusion adds)
+            const int di = c / CPD;
             const int nout = di == 0 ? NOUT1 : NOUT;
             const int cb = di == 0 ? 0 : NOUT1 + (di - 1) * NOUT;
+            // Addresses are (uniform per register) + (one per-lane offset): buffer stores/loads with
+            // the channel-plane offset in an SGPR keep the epilogue down to two address VGPRs.
 #pragma unroll
             for (int r = 0; r < M::NACC; ++r) {
-                const int ch = M::row(r, kq);
-                if (ch < nout) {
-                    const int c = cb + ch;
-                    float *orow = a.out + (long long)n * a.out_sn + (long long)c * a.out_sc + a.out_off +
-                                  y * a.out_pitch + x0 + px;
-                    const float *rrow = nullptr;
-                    if (RES)
-                        rrow = a.res + (long long)n * a.res_sn + (long long)c * a.res_sc + a.res_off +
-                               y * a.res_pitch + x0 + px;
-                    float scale = 1.0f, shift = 0.0f, alpha = 1.0f;
-                    if (BNACT) {
-                        scale = bnp[c];
-                        shift = bnp[COUT + c];
-                        alpha = bnp[2 * COUT + c];
-                    }
+                const int ch0 = M::row(r, 0);                 // channel held by k-group 0; group kq holds ch0 + kq*KSTR
+                const bool live = ch0 + kq * KSTR < nout;
+                const int so = (cb + ch0) * a.out_sc * 4;
+                const int sr = (cb + ch0) * a.res_sc * 4;
+                float scale = 1.0f, shift = 0.0f, alpha = 1.0f;
+                if (BNACT) {
+                    const float *bp = bnp + (live ? cb + ch0 + kq * KSTR : 0);
+                    scale = bp[0];
+                    shift = bp[COUT];
+                    alpha = bp[2 * COUT];
+                }
 #pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        if (x0 + p * MT + px < a.W) {
-                            float v = acc[p][r];
-                            if (RES)
-                                v += rrow[p * MT];
-                            if (BNACT) {
-                                v = v * scale + shift;
-                                v = v > 0.0f ? v : alpha * v;
-                            }
-                            orow[p * MT] = v;
+                for (int p = 0; p < P; ++p) {
+                    if (live && x0 + p * MT + px < a.W) {
+                        float v = acc[p][r];
+                        if (RES)
+                            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, vres + p * MT * 4, sr + sres, 0));
+                        if (BNACT) {
+                            v = v * scale + shift;
+                            v = v > 0.0f ? v : alpha * v;
                         }
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vout + p * MT * 4, so + sout, 0);
                     }
                 }
             }
+        };
+
+        {
+            const ChunkAddr first = locate(0);
+#pragma unroll
+            for (int j = 0; j < TXU; ++j)
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    fetch(first, j, u);
         }
+        for (int c = 0; c < NCHUNK; ++c)
+            compute(c);
     }
 }
 

@@ -289,12 +289,14 @@ static ConvArgs conv_args(const Act &in, const float *wpack, const Act &out, con
     a.out_sc = out.sc;
     a.out_pitch = out.pitch;
     a.out_off = out.off;
+    a.out_img_bytes = (unsigned)(out.sn * sizeof(float));
     if (res) {
         a.res = res->base;
         a.res_sn = res->sn;
         a.res_sc = res->sc;
         a.res_pitch = res->pitch;
         a.res_off = res->off;
+        a.res_img_bytes = (unsigned)(res->sn * sizeof(float));
     }
     a.N = n;
     a.H = out.H;
