@@ -74,8 +74,8 @@ struct ConvArgs {
     int total_tasks;
 };
 
-template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int TXU,
-          int UNR, bool BNACT, bool RES>
+template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int D,
+          bool BNACT, bool RES>
 __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 {
     using M = Mfma<MT>;
@@ -85,19 +85,17 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     constexpr int COUT = NOUT1 + (NDIL - 1) * NOUT;
     constexpr int TYN = TAPS == 9 ? 3 : 1;
     constexpr int TXN = TAPS == 9 ? 3 : 1;
-    constexpr int TXG = TXN / TXU, SG = NSTEP / UNR;
-    constexpr int CPD = TYN * TXG * SG;   // chunks per dilation
-    constexpr int NCHUNK = NDIL * CPD;
-    static_assert(CINP % KL == 0 && NSTEP % UNR == 0, "k-steps must tile");
+    constexpr int SPD = TYN * NSTEP * TXN;   // k-steps per dilation, order (ty, cin-group, tx): tx fastest
+    constexpr int NTOT = NDIL * SPD;
+    constexpr int NCHUNK = NTOT / D;
+    static_assert(CINP % KL == 0, "k-steps must tile");
     static_assert(TAPS == 1 || TAPS == 9, "1x1 or 3x3");
-    static_assert(TXN % TXU == 0, "tap unroll");
+    static_assert(SPD % D == 0, "ring depth must divide the steps of one dilation");
     static_assert(NROW <= MT, "one MFMA row block");
+    constexpr int KSTR = 4;   // accumulator rows of k-group kq sit KSTR*kq above those of group 0 (both shapes)
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    for (int i = tid * 4; i < a.wfloats; i += WAVES * 64 * 4)
-        *reinterpret_cast<float4 *>(lds + i) = *reinterpret_cast<const float4 *>(a.wpack + i);
-    __syncthreads();
     const float *bnp = lds + NDIL * TAPS * CINP * NROW;   // [scale | shift | alpha][COUT]
 
     const int lane = tid & 63;
@@ -105,7 +103,6 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     const int px = lane % MT, kq = lane / MT;
     const int voff = (kq * a.in_sc + px * STRIDE) * 4;
     const int lbase = kq * NROW + (px < NROW ? px : NROW - 1);
-    constexpr int KSTR = MT == 32 ? 4 : 4;   // accumulator rows of k-group kq sit KSTR*kq above those of group 0
     const int vout = (kq * KSTR * a.out_sc + px) * 4;
     const int vres = RES ? (kq * KSTR * a.res_sc + px) * 4 : 0;
 
@@ -120,10 +117,13 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     const int t0 = (int)((long long)a.total_tasks * wg / ((long long)G * WAVES));
     const int t1 = (int)((long long)a.total_tasks * (wg + 1) / ((long long)G * WAVES));
     const int tasks_per_img = a.H * a.strips;
+    bool staged = false;
 
-    for (int task = t0; task < t1; ++task) {
-        const int n = task / tasks_per_img;
-        const int rem = task - n * tasks_per_img;
+    for (int task = t0; task < t1 || !staged; ++task) {
+        const bool idle = task >= t1;   // a wave without work still has to help stage the weights
+        const int tk = idle ? (a.total_tasks - 1) : task;
+        const int n = tk / tasks_per_img;
+        const int rem = tk - n * tasks_per_img;
         const int y = rem / a.strips;
         const int x0 = (rem - y * a.strips) * (P * MT);
 
@@ -139,111 +139,136 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 
         typename M::acc_t acc[P];
 
-        // The k-loop is a flat sequence of NCHUNK chunks, chunk = (dilation, tap row, TXU taps, UNR
-        // k-steps), software-pipelined by hand with ONE register set used as a ring: right after the
-        // MFMAs of k-step u of chunk c have consumed their operands, the same registers are refilled
-        // with k-step u of chunk c+1.  Every load therefore has a whole chunk of MFMA work (thousands
-        // of cycles) to land, at no extra register cost.  (The first version waited on loads it had
-        // just issued: SQ_WAIT_ANY 57 % of wave cycles, MFMA pipe 42 % busy.)
-        struct ChunkAddr {
-            int soff[TXU];
-            const float *wl[TXU];
-        };
-        auto locate = [&](int c) {
-            ChunkAddr ca;
-            const int di = c / CPD;
-            int r = c - di * CPD;
-            const int ty = r / (TXG * SG);
-            r -= ty * (TXG * SG);
-            const int tg = r / SG;
-            const int s0 = (r - tg * SG) * UNR;
-            const int tx0 = tg * TXU;
-            const int d = 1 << di;
-#pragma unroll
-            for (int j = 0; j < TXU; ++j) {
-                const int tap = TAPS == 9 ? ty * 3 + tx0 + j : 0;
-                const int toff = TAPS == 9 ? ((ty - 1) * a.in_pitch + (tx0 + j - 1)) * d : 0;
-                ca.soff[j] = sbase + toff * 4 + s0 * KL * a.in_sc * 4;
-                ca.wl[j] = lds + (di * TAPS + tap) * (CINP * NROW) + s0 * KL * NROW + lbase;
-            }
-            return ca;
-        };
-        float aq[TXU][UNR], bq[TXU][UNR][P];
-        auto fetch = [&](const ChunkAddr &ca, int j, int u) {
-            aq[j][u] = ca.wl[j][u * KL * NROW];
+        // The k-loop is one flat sequence of NTOT k-steps run through a ring of D operand slots:
+        // right after the MFMAs of step i have consumed slot i % D, the slot is refilled with step
+        // i + D.  Every load therefore has D steps of MFMA work (thousands of cycles) to land, at
+        // the register cost of a single operand set.  (The first version waited on loads it had just
+        // issued: SQ_WAIT_ANY 57 % of wave cycles, MFMA pipe 42 % busy.)  The three horizontal taps
+        // of a row are consecutive steps, so two of three B loads hit lines the wave has just pulled
+        // into L1.
+        float aq[D], bq[D][P];
+        auto fetch_b = [&](int i, int u) {
+            const int di = i / SPD;
+            int r = i - di * SPD;
+            const int ty = r / (NSTEP * TXN);
+            r -= ty * (NSTEP * TXN);
+            const int sidx = r / TXN;
+            const int tx = r - sidx * TXN;
+            const int toff = TAPS == 9 ? ((ty - 1) * a.in_pitch + (tx - 1)) << di : 0;
+            const int soff = sbase + (toff + sidx * KL * a.in_sc) * 4;
 #pragma unroll
             for (int p = 0; p < P; ++p)
-                bq[j][u][p] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + p * MT * STRIDE * 4,
-                                                                ca.soff[j] + u * KL * a.in_sc * 4, 0));
+                bq[u][p] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + p * MT * STRIDE * 4, soff, 0));
         };
-        auto compute = [&](int c) {
-            if (c % CPD == 0 && c < 2 * CPD) {   // d1 and d2 start fresh; d4, d8, d16 keep adding (HFF)
+        auto fetch_a = [&](int i, int u) {
+            const int di = i / SPD;
+            int r = i - di * SPD;
+            const int ty = r / (NSTEP * TXN);
+            r -= ty * (NSTEP * TXN);
+            const int sidx = r / TXN;
+            const int tx = r - sidx * TXN;
+            const int tap = TAPS == 9 ? ty * 3 + tx : 0;
+            aq[u] = lds[((di * TAPS + tap) * CINP + sidx * KL) * NROW + lbase];
+        };
+
+        // prologue: the first D steps' activations are requested before the weights are staged, so
+        // their latency overlaps the LDS fill
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+            fetch_b(u, u);
+        if (!staged) {
+            for (int i = tid * 4; i < a.wfloats; i += WAVES * 64 * 4)
+                *reinterpret_cast<float4 *>(lds + i) = *reinterpret_cast<const float4 *>(a.wpack + i);
+            __syncthreads();
+            staged = true;
+        }
+        if (idle)
+            break;
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+            fetch_a(u, u);
+
+        for (int c = 0; c < NCHUNK; ++c) {
+            const int i0 = c * D;
+            if (i0 % SPD == 0 && i0 < 2 * SPD) {   // d1 and d2 start fresh; d4, d8, d16 keep adding (HFF)
 #pragma unroll
                 for (int p = 0; p < P; ++p)
                     acc[p] = (typename M::acc_t)(0.0f);
             }
-            const ChunkAddr nx = locate(c + 1 < NCHUNK ? c + 1 : c);   // the last chunk refetches itself (unused)
+            const int nx = (c + 1 < NCHUNK ? i0 + D : i0);   // the last chunk refetches itself (unused)
 #pragma unroll
-            for (int j = 0; j < TXU; ++j)
+            for (int u = 0; u < D; ++u) {
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-#pragma unroll
-                    for (int p = 0; p < P; ++p)
-                        acc[p] = M::run(aq[j][u], bq[j][u][p], acc[p]);
-                    fetch(nx, j, u);
-                    // pin the ring order: left alone, hipcc sinks the refill loads to the end of the
-                    // chunk, which shrinks the prefetch distance from a chunk to a few k-steps
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            if ((c + 1) % CPD != 0)
-                return;
+                for (int p = 0; p < P; ++p)
+                    acc[p] = M::run(aq[u], bq[u][p], acc[p]);
+                fetch_b(nx + u, u);
+                fetch_a(nx + u, u);
+                // pin the ring order: left alone, hipcc sinks the refill loads to the end of the
+                // chunk, which shrinks the prefetch distance from D steps to a few
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if ((i0 + D) % SPD != 0)
+                continue;
             // last chunk of a dilation: write this branch's concat slot (the accumulator keeps
             // running for the fusion adds)
-            const int di = c / CPD;
+            const int di = i0 / SPD;
             const int nout = di == 0 ? NOUT1 : NOUT;
             const int cb = di == 0 ? 0 : NOUT1 + (di - 1) * NOUT;
-            // Addresses are (uniform per register) + (one per-lane offset): buffer stores/loads with
-            // the channel-plane offset in an SGPR keep the epilogue down to two address VGPRs.
+            // Branch-free epilogue.  Addresses are (uniform per accumulator register, in an SGPR) +
+            // (one per-lane offset); lanes that hold nothing to store (channel >= nout, x >= W) get
+            // an offset beyond num_records, which the buffer range check turns into a dropped store /
+            // zero load -- no exec-mask branches, so the residual loads of a register group are all
+            // in flight together (the branchy first version waited vmcnt(0) per element).
+            int vo[P], vr[P];
 #pragma unroll
-            for (int r = 0; r < M::NACC; ++r) {
-                const int ch0 = M::row(r, 0);                 // channel held by k-group 0; group kq holds ch0 + kq*KSTR
-                const bool live = ch0 + kq * KSTR < nout;
-                const int so = (cb + ch0) * a.out_sc * 4;
-                const int sr = (cb + ch0) * a.res_sc * 4;
-                float scale = 1.0f, shift = 0.0f, alpha = 1.0f;
-                if (BNACT) {
-                    const float *bp = bnp + (live ? cb + ch0 + kq * KSTR : 0);
-                    scale = bp[0];
-                    shift = bp[COUT];
-                    alpha = bp[2 * COUT];
+            for (int p = 0; p < P; ++p) {
+                const bool xok = x0 + p * MT + px < a.W;
+                vo[p] = xok ? vout + p * MT * 4 : (int)0x7ffffff0;
+                vr[p] = xok ? vres + p * MT * 4 : (int)0x7ffffff0;
+            }
+            constexpr int RG = 4;   // accumulator registers per group
+#pragma unroll
+            for (int g = 0; g < M::NACC / RG; ++g) {
+                float resv[RG][P];
+                if (RES) {
+#pragma unroll
+                    for (int rr = 0; rr < RG; ++rr) {
+                        const int ch0 = M::row(g * RG + rr, 0);
+                        const int sr = (cb + ch0) * a.res_sc * 4 + sres;
+#pragma unroll
+                        for (int p = 0; p < P; ++p)
+                            resv[rr][p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, vr[p], sr, 0));
+                    }
                 }
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    if (live && x0 + p * MT + px < a.W) {
+                for (int rr = 0; rr < RG; ++rr) {
+                    const int r = g * RG + rr;
+                    const int ch0 = M::row(r, 0);   // channel held by k-group 0; group kq holds ch0 + kq*KSTR
+                    const bool live = ch0 + kq * KSTR < nout;
+                    const int so = (cb + ch0) * a.out_sc * 4 + sout;
+                    float scale = 1.0f, shift = 0.0f, alpha = 1.0f;
+                    if (BNACT) {
+                        const float *bp = bnp + (live ? cb + ch0 + kq * KSTR : 0);
+                        scale = bp[0];
+                        shift = bp[COUT];
+                        alpha = bp[2 * COUT];
+                    }
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
                         float v = acc[p][r];
                         if (RES)
-                            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, vres + p * MT * 4, sr + sres, 0));
+                            v += resv[rr][p];
                         if (BNACT) {
                             v = v * scale + shift;
                             v = v > 0.0f ? v : alpha * v;
                         }
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vout + p * MT * 4, so + sout, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout,
+                                                              live ? vo[p] : (int)0x7ffffff0, so, 0);
                     }
                 }
             }
-        };
-
-        {
-            const ChunkAddr first = locate(0);
-#pragma unroll
-            for (int j = 0; j < TXU; ++j)
-#pragma unroll
-                for (int u = 0; u < UNR; ++u)
-                    fetch(first, j, u);
         }
-        for (int c = 0; c < NCHUNK; ++c)
-            compute(c);
     }
 }
 
@@ -256,11 +281,11 @@ constexpr int conv_wfloats(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT, bo
     return (n + 3) / 4 * 4;
 }
 
-template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int TXU,
-          int UNR, bool BNACT, bool RES>
+template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int D,
+          bool BNACT, bool RES>
 gs_status launch_conv_mfma(ConvArgs a, int num_cus, hipStream_t stream)
 {
-    auto kern = conv_mfma_kernel<MT, WAVES, CINP, TAPS, STRIDE, NDIL, NOUT1, NOUT, P, TXU, UNR, BNACT, RES>;
+    auto kern = conv_mfma_kernel<MT, WAVES, CINP, TAPS, STRIDE, NDIL, NOUT1, NOUT, P, D, BNACT, RES>;
     a.strips = cdiv(a.W, P * MT);
     a.total_tasks = a.N * a.H * a.strips;
     a.wfloats = conv_wfloats(CINP, TAPS, NDIL, NOUT1, NOUT, BNACT);
@@ -271,10 +296,11 @@ gs_status launch_conv_mfma(ConvArgs a, int num_cus, hipStream_t stream)
                                    (int)lds_bytes));
         attr_done = true;
     }
-    // workgroups resident per CU by LDS, capped so a wave gets at least one task
+    // workgroups resident per CU by LDS and by wave slots (WAVES <= 8: up to 2 waves per SIMD; the
+    // 12/16-wave variants fill the CU with one workgroup)
     int per_cu = (int)((160 * 1024) / (lds_bytes + 256));
     if (per_cu < 1) per_cu = 1;
-    const int wave_slots = 8 / WAVES > 0 ? 8 / WAVES : 1;   // stay at <= 2 waves per SIMD
+    const int wave_slots = WAVES >= 8 ? 1 : 8 / WAVES;
     if (per_cu > wave_slots) per_cu = wave_slots;
     int grid = num_cus * per_cu;
     const int need = cdiv(a.total_tasks, WAVES);

@@ -2,6 +2,7 @@
 // Reference path replaced: module/espnet/test/Model.py ESPNet.forward (:341-378) /
 // ESPNet_Encoder.forward (:273-304) called from module/espnet/test/VisualizeResults_iou.py:123.
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <string>
@@ -25,13 +26,14 @@ void set_error(const char *fmt, ...)
 
 // ------------------------------------------------------------------------------------------
 // kernel configurations (template arguments of conv_mfma_kernel); see DESIGN.md "kernels"
-//                       MT WAVES CINP TAPS STRIDE NDIL NOUT1 NOUT  P TXU UNR
-#define CFG_L2_C1S       16, 8,   20,  9,   2,     1,   12,   12,   8, 1,  5
-#define CFG_L2_C1        16, 8,   64,  1,   1,     1,   12,   12,   8, 1,  8
-#define CFG_L2_BR        16, 8,   12,  9,   1,     5,   16,   12,   8, 3,  3
-#define CFG_L3_C1S       32, 8,   132, 9,   2,     1,   25,   25,   4, 1,  11
-#define CFG_L3_C1        32, 8,   128, 1,   1,     1,   25,   25,   4, 1,  16
-#define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 1,  13
+//                       MT WAVES CINP TAPS STRIDE NDIL NOUT1 NOUT  P  D
+#define CFG_L2_C1S       16, 8,   20,  9,   2,     1,   12,   12,   8, 9
+#define CFG_L2_C1        16, 8,   64,  1,   1,     1,   12,   12,   8, 8
+#define CFG_L2_BR        16, 8,   12,  9,   1,     5,   16,   12,   8, 9
+#define CFG_L3_C1S       32, 8,   132, 9,   2,     1,   25,   25,   4, 11
+#define CFG_L3_C1        32, 8,   128, 1,   1,     1,   25,   25,   4, 16
+#define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 13
+#define CFG_L3_BR_W16    32, 16,  26,  9,   1,     5,   28,   25,   2, 13
 
 enum KernelId {
     K_STEM, K_POOL, K_L2_C1S, K_L2_DOWN, K_L2_C1, K_L2_ESP, K_CAT_B2, K_L3_C1S, K_L3_DOWN, K_L3_C1, K_L3_ESP,
@@ -50,6 +52,7 @@ struct Model {
     int classes = 0, p = 0, q = 0;
     bool encoder_only = false;
     int device = 0, num_cus = 256;
+    int variant = 0;   // GS_VARIANT env: kernel A/B experiments (0 = shipped configuration)
     float *dblob = nullptr;
     // offsets (floats) into dblob
     long long w1, bn1, b1, b2, b3, wcls, br, wup3, w3c, cbr0, wcc, bncc, wup2, bnu2, wconv, bnconv, wclassifier;
@@ -396,6 +399,8 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             return launch_conv_mfma<CFG_L3_C1, false, false>(conv_args(m->cc[cur3], wb + m->l3[i].c1, m->r3, nullptr, n), m->num_cus, s);
         });
         L.run(K_L3_ESP, px3 * (25 * 9 * 128 * 2), [&] {
+            if (m->variant == 1)
+                return launch_conv_mfma<CFG_L3_BR_W16, true, true>(conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n), m->num_cus, s);
             return launch_conv_mfma<CFG_L3_BR, true, true>(conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n), m->num_cus, s);
         });
         cur3 = nxt;
@@ -514,6 +519,8 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
         return GS_ERR_NODEVICE;
     }
     m.num_cus = prop.multiProcessorCount;
+    if (const char *v = std::getenv("GS_VARIANT"))
+        m.variant = std::atoi(v);
 
     WeightTable t;
     t.blob = blob;
