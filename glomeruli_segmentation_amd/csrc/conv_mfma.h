@@ -69,15 +69,27 @@ struct ConvArgs {
     const float *res;
     long long res_sn;
     int res_sc, res_pitch, res_off;
+    // optional second output (F_DUAL): channel c of this kernel lands in plane out2_coff + c
+    float *out2;
+    long long out2_sn;
+    int out2_sc, out2_pitch, out2_off, out2_coff;
+    unsigned out2_img_bytes;
     int N, H, W;   // OUTPUT size
     int strips;    // pixel strips per output row
     int total_tasks;
 };
 
-template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int D,
-          bool BNACT, bool RES>
+// epilogue flags
+constexpr int F_BNACT = 1;   // folded BatchNorm + PReLU on the way out
+constexpr int F_RES = 2;     // add the residual input before BN (ESP block, Model.py:211-213)
+constexpr int F_NOSTORE = 4; // skip the primary store (the block output is only consumed through out2)
+constexpr int F_DUAL = 8;    // second store into a concat buffer through a second BN+PReLU: the b2 / b3
+                             // "BR over a torch.cat" stages (Model.py:359) fused into the producers
+
+template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int D, int FLAGS>
 __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 {
+    constexpr bool BNACT = FLAGS & F_BNACT, RES = FLAGS & F_RES, STORE1 = !(FLAGS & F_NOSTORE), DUAL = FLAGS & F_DUAL;
     using M = Mfma<MT>;
     constexpr int KL = M::KL;
     constexpr int NSTEP = CINP / KL;
@@ -105,6 +117,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     const int lbase = kq * NROW + (px < NROW ? px : NROW - 1);
     const int vout = (kq * KSTR * a.out_sc + px) * 4;
     const int vres = RES ? (kq * KSTR * a.res_sc + px) * 4 : 0;
+    const int vout2 = DUAL ? (kq * KSTR * a.out2_sc + px) * 4 : 0;
 
     // Each wave takes a contiguous range of tasks; workgroups that share an XCD (equal
     // blockIdx % 8 under round-robin dispatch: speed only) take neighbouring ranges, so one XCD's
@@ -136,6 +149,9 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(RES ? a.res + (long long)n * a.res_sn : a.in), 0, RES ? a.res_img_bytes : 0u, 0x00020000);
         const int sres = RES ? (a.res_off + y * a.res_pitch + x0) * 4 : 0;
+        const __amdgpu_buffer_rsrc_t rout2 = __builtin_amdgcn_make_buffer_rsrc(
+            DUAL ? a.out2 + (long long)n * a.out2_sn : a.out, 0, DUAL ? a.out2_img_bytes : 0u, 0x00020000);
+        const int sout2 = DUAL ? (a.out2_off + y * a.out2_pitch + x0) * 4 : 0;
 
         typename M::acc_t acc[P];
 
@@ -220,12 +236,13 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
             // an offset beyond num_records, which the buffer range check turns into a dropped store /
             // zero load -- no exec-mask branches, so the residual loads of a register group are all
             // in flight together (the branchy first version waited vmcnt(0) per element).
-            int vo[P], vr[P];
+            int vo[P], vr[P], vo2[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const bool xok = x0 + p * MT + px < a.W;
                 vo[p] = xok ? vout + p * MT * 4 : (int)0x7ffffff0;
                 vr[p] = xok ? vres + p * MT * 4 : (int)0x7ffffff0;
+                vo2[p] = xok ? vout2 + p * MT * 4 : (int)0x7ffffff0;
             }
             constexpr int RG = 4;   // accumulator registers per group
 #pragma unroll
@@ -247,12 +264,18 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                     const int ch0 = M::row(r, 0);   // channel held by k-group 0; group kq holds ch0 + kq*KSTR
                     const bool live = ch0 + kq * KSTR < nout;
                     const int so = (cb + ch0) * a.out_sc * 4 + sout;
-                    float scale = 1.0f, shift = 0.0f, alpha = 1.0f;
+                    const int so2 = DUAL ? (a.out2_coff + cb + ch0) * a.out2_sc * 4 + sout2 : 0;
+                    float scale = 1.0f, shift = 0.0f, alpha = 1.0f, scale2 = 1.0f, shift2 = 0.0f, alpha2 = 1.0f;
                     if (BNACT) {
                         const float *bp = bnp + (live ? cb + ch0 + kq * KSTR : 0);
                         scale = bp[0];
                         shift = bp[COUT];
                         alpha = bp[2 * COUT];
+                        if (DUAL) {
+                            scale2 = bp[3 * COUT];
+                            shift2 = bp[4 * COUT];
+                            alpha2 = bp[5 * COUT];
+                        }
                     }
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
@@ -263,8 +286,15 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                             v = v * scale + shift;
                             v = v > 0.0f ? v : alpha * v;
                         }
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout,
-                                                              live ? vo[p] : (int)0x7ffffff0, so, 0);
+                        if (STORE1)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout,
+                                                                  live ? vo[p] : (int)0x7ffffff0, so, 0);
+                        if (DUAL) {
+                            float v2 = v * scale2 + shift2;
+                            v2 = v2 > 0.0f ? v2 : alpha2 * v2;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2), rout2,
+                                                                  live ? vo2[p] : (int)0x7ffffff0, so2, 0);
+                        }
                     }
                 }
             }
@@ -273,22 +303,21 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 }
 
 // number of floats of the LDS image for a configuration (weights, then 3*COUT BN/PReLU params)
-constexpr int conv_wfloats(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT, bool bn)
+constexpr int conv_wfloats(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT, bool bn, bool dual = false)
 {
     const int nrow = NOUT1 > NOUT ? NOUT1 : NOUT;
     const int cout = NOUT1 + (NDIL - 1) * NOUT;
-    const int n = NDIL * TAPS * CINP * nrow + (bn ? 3 * cout : 0);
+    const int n = NDIL * TAPS * CINP * nrow + (bn ? 3 * cout : 0) + (dual ? 3 * cout : 0);
     return (n + 3) / 4 * 4;
 }
 
-template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int D,
-          bool BNACT, bool RES>
+template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int D, int FLAGS>
 gs_status launch_conv_mfma(ConvArgs a, int num_cus, hipStream_t stream)
 {
-    auto kern = conv_mfma_kernel<MT, WAVES, CINP, TAPS, STRIDE, NDIL, NOUT1, NOUT, P, D, BNACT, RES>;
+    auto kern = conv_mfma_kernel<MT, WAVES, CINP, TAPS, STRIDE, NDIL, NOUT1, NOUT, P, D, FLAGS>;
     a.strips = cdiv(a.W, P * MT);
     a.total_tasks = a.N * a.H * a.strips;
-    a.wfloats = conv_wfloats(CINP, TAPS, NDIL, NOUT1, NOUT, BNACT);
+    a.wfloats = conv_wfloats(CINP, TAPS, NDIL, NOUT1, NOUT, FLAGS & F_BNACT, FLAGS & F_DUAL);
     const size_t lds_bytes = (size_t)a.wfloats * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {

@@ -34,15 +34,16 @@ void set_error(const char *fmt, ...)
 #define CFG_L3_C1        32, 8,   128, 1,   1,     1,   25,   25,   4, 16
 #define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 13
 #define CFG_L3_BR_W16    32, 16,  26,  9,   1,     5,   28,   25,   2, 13
+#define CFG_DEC_CONV     16, 8,   28,  9,   1,     1,   5,    5,    8, 9
 
 enum KernelId {
     K_STEM, K_POOL, K_L2_C1S, K_L2_DOWN, K_L2_C1, K_L2_ESP, K_CAT_B2, K_L3_C1S, K_L3_DOWN, K_L3_C1, K_L3_ESP,
-    K_DEC1, K_DEC2, K_DEC3, K_DEC4, K_COUNT
+    K_DEC1, K_DEC2, K_DEC3, K_DEC_CONV, K_DEC4, K_COUNT
 };
 static const char *kKernelNames[K_COUNT] = {
     "stem_kernel", "pool_kernel", "conv_l2_reduce_s2", "conv_l2_down_branches", "conv_l2_reduce_1x1",
     "conv_l2_esp_branches", "cat_b2_kernel", "conv_l3_reduce_s2", "conv_l3_down_branches", "conv_l3_reduce_1x1",
-    "conv_l3_esp_branches", "dec1_kernel", "dec2_kernel", "dec3_kernel", "dec4_kernel"};
+    "conv_l3_esp_branches", "dec1_kernel", "dec2_kernel", "dec3_kernel", "conv_dec_cbr", "dec4_kernel"};
 
 struct PackedConv {   // float offsets into the device weight blob
     long long c1 = -1, br = -1;
@@ -55,7 +56,7 @@ struct Model {
     int variant = 0;   // GS_VARIANT env: kernel A/B experiments (0 = shipped configuration)
     float *dblob = nullptr;
     // offsets (floats) into dblob
-    long long w1, bn1, b1, b2, b3, wcls, br, wup3, w3c, cbr0, wcc, bncc, wup2, bnu2, wconv, bnconv, wclassifier;
+    long long w1, bn1, b1, b2, b3, wcls, br, wup3, w3c, cbr0, wcc, bncc, wup2, bnu2, wconv, wclassifier;
     PackedConv l2_0;
     std::vector<PackedConv> l2, l3;
     PackedConv l3_0;
@@ -64,7 +65,7 @@ struct Model {
     void *ws = nullptr;
     size_t ws_bytes = 0;
     int ws_n = 0, ws_h = 0, ws_w = 0;
-    Act a0, inp1, inp2, r2, bb[3], a1, r3, cc[3], o2c, tt, ee;
+    Act a0, inp1, inp2, r2, bb[3], a1, r3, cc[3], o2c, tt, ee, ff;
     float *prob = nullptr;   // ensemble scratch
     size_t prob_bytes = 0;
     std::map<std::string, std::pair<Act, int>> stages;   // name -> (activation, channels) of the last forward
@@ -151,7 +152,8 @@ static void pack_conv(const float *w, int cout, int cin, int k, float *dst, int 
                 dst[(((size_t)slot * taps + tap) * cinp + ci) * nrow + co] = w[((size_t)co * cin + ci) * k * k + tap];
 }
 
-static bool pack_block(WeightTable &t, BlobBuilder &bb, const std::string &pre, bool down, int level, PackedConv &pc)
+static bool pack_block(WeightTable &t, BlobBuilder &bb, const std::string &pre, bool down, int level, PackedConv &pc,
+                       const float *dual = nullptr, int dual_coff = 0, int dual_c = 0)
 {
     // level 2: cin 19 (down) / 64, n = 12, n1 = 16;  level 3: cin 131 (down) / 128, n = 25, n1 = 28
     const int n = level == 2 ? 12 : 25, n1 = level == 2 ? 16 : 28, nOut = n1 + 4 * n;
@@ -166,7 +168,7 @@ static bool pack_block(WeightTable &t, BlobBuilder &bb, const std::string &pre, 
     pack_conv(wc1, n, cin, down ? 3 : 1, bb.data.data() + pc.c1, 0, taps, cinp, n);
 
     const int rcinp = (n + kl - 1) / kl * kl;
-    pc.br = bb.reserve(conv_wfloats(rcinp, 9, 5, n1, n, true));
+    pc.br = bb.reserve(conv_wfloats(rcinp, 9, 5, n1, n, true, dual != nullptr));
     static const char *dn[5] = {".d1", ".d2", ".d4", ".d8", ".d16"};
     for (int di = 0; di < 5; ++di) {
         const int co = di == 0 ? n1 : n;
@@ -177,6 +179,10 @@ static bool pack_block(WeightTable &t, BlobBuilder &bb, const std::string &pre, 
     }
     float *bnp = bb.data.data() + pc.br + (size_t)5 * 9 * rcinp * n1;
     // DownSamplerB: self.bn / self.act (Model.py:141-142); ESP block: self.bn = BR(nOut) (Model.py:184)
+    if (dual)   // slice of the following concat's BR parameters, same [scale | shift | alpha][nOut] layout
+        for (int j = 0; j < 3; ++j)
+            for (int c = 0; c < nOut; ++c)
+                bnp[(3 + j) * nOut + c] = dual[j * dual_c + dual_coff + c];
     return down ? fold_bn(t, pre + ".bn", pre + ".act", nOut, bnp) : fold_bn(t, pre + ".bn.bn", pre + ".bn.act", nOut, bnp);
 }
 
@@ -206,7 +212,10 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
     }
     const int cls = m->classes;
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8;
-    m->a0 = make_act(19, 20, H1, W1, 1, 0, 4, 4);     // read by the stride-2 3x3 (needs top/left zero pad)
+    // output0_cat (planes 0..18) shares one buffer with comb_l2_l3 (planes 20..24, written by dec3): the
+    // decoder's conv CBR(19+classes, classes, 3) then reads its torch.cat input (Model.py:375) as ONE
+    // 28-plane activation (planes 19 and 25..27 stay zero), with zero pad on all four sides
+    m->a0 = make_act(19, 28, H1, W1, 1, 1, 4, 4);
     m->inp1 = make_act(3, 3, H1, W1, 0, 0, 0, 0);
     m->inp2 = make_act(3, 3, H2, W2, 0, 0, 0, 0);
     m->r2 = make_act(12, 12, H2, W2, 16, 16, 16, 16);  // dilation up to 16
@@ -218,9 +227,9 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
         m->cc[i] = make_act(128, 128, H3, W3, 0, 0, 0, 0);
     m->o2c = make_act(cls, cls, H2, W2, 0, 0, 0, 0);
     m->tt = make_act(2 * cls, 2 * cls, H2, W2, 0, 0, 0, 0);
-    m->ee = make_act(cls, cls, H1, W1, 0, 0, 0, 0);
+    m->ff = make_act(cls, cls, H1, W1, 0, 0, 0, 0);
     Act *all[] = {&m->a0, &m->inp1, &m->inp2, &m->r2, &m->bb[0], &m->bb[1], &m->bb[2], &m->a1, &m->r3,
-                  &m->cc[0], &m->cc[1], &m->cc[2], &m->o2c, &m->tt, &m->ee};
+                  &m->cc[0], &m->cc[1], &m->cc[2], &m->o2c, &m->tt, &m->ff};
     const size_t slack = 64 * 1024;   // strips may over-read past a buffer's last row (masked lanes only)
     size_t total = 0;
     for (Act *a : all)
@@ -236,6 +245,9 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
         a->base = reinterpret_cast<float *>(static_cast<char *>(ws) + at);
         at += round_up(a->bytes(n) + slack, 256);
     }
+    m->ee = m->a0;   // comb_l2_l3 = planes 20.. of the output0_cat buffer
+    m->ee.base = m->a0.base + (long long)20 * m->a0.sc;
+    m->ee.C = cls;
     m->ws = ws;
     m->ws_bytes = total;
     m->ws_n = n;
@@ -350,7 +362,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     });
     L.run(K_POOL, 0, [&] {
         hipLaunchKernelGGL(pool_kernel, dim3(blocks_for((long long)n * 3 * H2 * W2)), dim3(256), 0, s, view(m->inp1),
-                           view(m->inp2), n, 3);
+                           view(m->inp2), n, 3, m->p > 0 ? wb + m->b2 : nullptr, view(m->a1), 128, 131);
         return GS_OK;
     });
     set_stage("b1", m->a0, 19);
@@ -358,50 +370,73 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
 
     // ---- level 2 (Model.py:351-357): DownSamplerB(19,64) then p ESP blocks
     L.run(K_L2_C1S, px2 * (19 * 9 * 12 * 2), [&] {
-        return launch_conv_mfma<CFG_L2_C1S, false, false>(conv_args(m->a0, wb + m->l2_0.c1, m->r2, nullptr, n), m->num_cus, s);
+        return launch_conv_mfma<CFG_L2_C1S, 0>(conv_args(m->a0, wb + m->l2_0.c1, m->r2, nullptr, n), m->num_cus, s);
     });
+    // b2 = BR(131) over cat([output1, output1_0, inp2]) (Model.py:359) is fused into its producers:
+    // the down-sampler stores output1_0 twice (raw for the ESP blocks, b2-normalised into planes
+    // 64..127 of output1_cat), the last ESP block stores only its b2-normalised form (planes 0..63)
+    // and the pool kernel writes planes 128..130.  With p == 0 the unfused cat kernel runs instead.
+    auto with_dual = [&](ConvArgs a, int coff) {
+        a.out2 = m->a1.base;
+        a.out2_sn = m->a1.sn;
+        a.out2_sc = m->a1.sc;
+        a.out2_pitch = m->a1.pitch;
+        a.out2_off = m->a1.off;
+        a.out2_coff = coff;
+        a.out2_img_bytes = (unsigned)(m->a1.sn * sizeof(float));
+        return a;
+    };
+    const bool fuse_b2 = m->p > 0;
     L.run(K_L2_DOWN, px2 * (12 * 9 * 64 * 2), [&] {
-        return launch_conv_mfma<CFG_L2_BR, true, false>(conv_args(m->r2, wb + m->l2_0.br, m->bb[0], nullptr, n), m->num_cus, s);
+        if (fuse_b2)
+            return launch_conv_mfma<CFG_L2_BR, F_BNACT | F_DUAL>(with_dual(conv_args(m->r2, wb + m->l2_0.br, m->bb[0], nullptr, n), 64), m->num_cus, s);
+        return launch_conv_mfma<CFG_L2_BR, F_BNACT>(conv_args(m->r2, wb + m->l2_0.br, m->bb[0], nullptr, n), m->num_cus, s);
     });
     set_stage("level2_0", m->bb[0], 64);
     int cur2 = 0;
     for (int i = 0; i < m->p; ++i) {
         const int nxt = cur2 == 1 ? 2 : 1;
+        const bool last = i == m->p - 1;
         L.run(K_L2_C1, px2 * (64 * 12 * 2), [&] {
-            return launch_conv_mfma<CFG_L2_C1, false, false>(conv_args(m->bb[cur2], wb + m->l2[i].c1, m->r2, nullptr, n), m->num_cus, s);
+            return launch_conv_mfma<CFG_L2_C1, 0>(conv_args(m->bb[cur2], wb + m->l2[i].c1, m->r2, nullptr, n), m->num_cus, s);
         });
         L.run(K_L2_ESP, px2 * (12 * 9 * 64 * 2), [&] {
-            return launch_conv_mfma<CFG_L2_BR, true, true>(conv_args(m->r2, wb + m->l2[i].br, m->bb[nxt], &m->bb[cur2], n), m->num_cus, s);
+            if (last)
+                return launch_conv_mfma<CFG_L2_BR, F_BNACT | F_RES | F_NOSTORE | F_DUAL>(
+                    with_dual(conv_args(m->r2, wb + m->l2[i].br, m->bb[nxt], &m->bb[cur2], n), 0), m->num_cus, s);
+            return launch_conv_mfma<CFG_L2_BR, F_BNACT | F_RES>(conv_args(m->r2, wb + m->l2[i].br, m->bb[nxt], &m->bb[cur2], n), m->num_cus, s);
         });
         cur2 = nxt;
-        set_stage("level2." + std::to_string(i), m->bb[cur2], 64);
+        if (!last)
+            set_stage("level2." + std::to_string(i), m->bb[cur2], 64);
     }
-    // ---- b2 (Model.py:359)
-    L.run(K_CAT_B2, 0, [&] {
-        hipLaunchKernelGGL(cat_b2_kernel, dim3(blocks_for((long long)n * 131 * H2 * W2)), dim3(256), 0, s, view(m->bb[cur2]),
-                           view(m->bb[0]), view(m->inp2), wb + m->b2, view(m->a1), n);
-        return GS_OK;
-    });
+    if (!fuse_b2) {
+        L.run(K_CAT_B2, 0, [&] {
+            hipLaunchKernelGGL(cat_b2_kernel, dim3(blocks_for((long long)n * 131 * H2 * W2)), dim3(256), 0, s, view(m->bb[cur2]),
+                               view(m->bb[0]), view(m->inp2), wb + m->b2, view(m->a1), n);
+            return GS_OK;
+        });
+    }
     set_stage("b2", m->a1, 131);
 
     // ---- level 3 (Model.py:361-366)
     L.run(K_L3_C1S, px3 * (131 * 9 * 25 * 2), [&] {
-        return launch_conv_mfma<CFG_L3_C1S, false, false>(conv_args(m->a1, wb + m->l3_0.c1, m->r3, nullptr, n), m->num_cus, s);
+        return launch_conv_mfma<CFG_L3_C1S, 0>(conv_args(m->a1, wb + m->l3_0.c1, m->r3, nullptr, n), m->num_cus, s);
     });
     L.run(K_L3_DOWN, px3 * (25 * 9 * 128 * 2), [&] {
-        return launch_conv_mfma<CFG_L3_BR, true, false>(conv_args(m->r3, wb + m->l3_0.br, m->cc[0], nullptr, n), m->num_cus, s);
+        return launch_conv_mfma<CFG_L3_BR, F_BNACT>(conv_args(m->r3, wb + m->l3_0.br, m->cc[0], nullptr, n), m->num_cus, s);
     });
     set_stage("level3_0", m->cc[0], 128);
     int cur3 = 0;
     for (int i = 0; i < m->q; ++i) {
         const int nxt = cur3 == 1 ? 2 : 1;
         L.run(K_L3_C1, px3 * (128 * 25 * 2), [&] {
-            return launch_conv_mfma<CFG_L3_C1, false, false>(conv_args(m->cc[cur3], wb + m->l3[i].c1, m->r3, nullptr, n), m->num_cus, s);
+            return launch_conv_mfma<CFG_L3_C1, 0>(conv_args(m->cc[cur3], wb + m->l3[i].c1, m->r3, nullptr, n), m->num_cus, s);
         });
         L.run(K_L3_ESP, px3 * (25 * 9 * 128 * 2), [&] {
             if (m->variant == 1)
-                return launch_conv_mfma<CFG_L3_BR_W16, true, true>(conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n), m->num_cus, s);
-            return launch_conv_mfma<CFG_L3_BR, true, true>(conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n), m->num_cus, s);
+                return launch_conv_mfma<CFG_L3_BR_W16, F_BNACT | F_RES>(conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n), m->num_cus, s);
+            return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES>(conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n), m->num_cus, s);
         });
         cur3 = nxt;
         set_stage("level3." + std::to_string(i), m->cc[cur3], 128);
@@ -460,12 +495,13 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             return GS_ERR_HIP;
         }
     }
-    L.run(K_DEC4, px1 * ((19 + CLS) * 9 * CLS * 2) + px1 * (CLS * CLS * 4 * 2), [&] {
+    L.run(K_DEC_CONV, px1 * ((19 + CLS) * 9 * CLS * 2), [&] {
+        return launch_conv_mfma<CFG_DEC_CONV, F_BNACT>(conv_args(m->a0, wb + m->wconv, m->ff, nullptr, n), m->num_cus, s);
+    });
+    set_stage("conv", m->ff, CLS);
+    L.run(K_DEC4, px1 * (CLS * CLS * 4 * 2), [&] {
         Dec4Args a{};
-        a.e = view(m->ee);
-        a.a0 = view(m->a0);
-        a.wc = wb + m->wconv;
-        a.bnc = wb + m->bnconv;
+        a.f = view(m->ff);
         a.wcl = wb + m->wclassifier;
         a.logits = logits;
         a.mask = mask;
@@ -538,12 +574,14 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
     m.bn1 = bb.push(tmp.data(), 48);
     if (!fold_bn(t, e + "b1.bn", e + "b1.act", 19, tmp.data())) return GS_ERR_INVALID;
     m.b1 = bb.push(tmp.data(), 57);
-    if (!pack_block(t, bb, e + "level2_0", true, 2, m.l2_0)) return GS_ERR_INVALID;
+    std::vector<float> b2f(3 * 131);
+    if (!fold_bn(t, e + "b2.bn", e + "b2.act", 131, b2f.data())) return GS_ERR_INVALID;
+    m.b2 = bb.push(b2f.data(), 393);
+    if (!pack_block(t, bb, e + "level2_0", true, 2, m.l2_0, p > 0 ? b2f.data() : nullptr, 64, 131)) return GS_ERR_INVALID;
     m.l2.resize(p);
     for (int i = 0; i < p; ++i)
-        if (!pack_block(t, bb, e + "level2." + std::to_string(i), false, 2, m.l2[i])) return GS_ERR_INVALID;
-    if (!fold_bn(t, e + "b2.bn", e + "b2.act", 131, tmp.data())) return GS_ERR_INVALID;
-    m.b2 = bb.push(tmp.data(), 393);
+        if (!pack_block(t, bb, e + "level2." + std::to_string(i), false, 2, m.l2[i], i == p - 1 ? b2f.data() : nullptr, 0, 131))
+            return GS_ERR_INVALID;
     if (!pack_block(t, bb, e + "level3_0", true, 3, m.l3_0)) return GS_ERR_INVALID;
     m.l3.resize(q);
     for (int i = 0; i < q; ++i)
@@ -570,9 +608,20 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
         if (!fold_bn(t, "up_l2.1.bn", "up_l2.1.act", c, tmp.data())) return GS_ERR_INVALID;
         m.bnu2 = bb.push(tmp.data(), 3 * c);
         if (!(w = t.get("conv.conv.weight", {c, 19 + c, 3, 3}))) return GS_ERR_INVALID;
-        m.wconv = bb.push(w, (size_t)c * (19 + c) * 9);
-        if (!fold_bn(t, "conv.bn", "conv.act", c, tmp.data())) return GS_ERR_INVALID;
-        m.bnconv = bb.push(tmp.data(), 3 * c);
+        {
+            // LDS image [tap][28 planes][c]: plane p < 19 is output0_cat channel p = cat channel c + p,
+            // plane 20 + j is comb_l2_l3 channel j = cat channel j (Model.py:375 cat order), rest zero
+            m.wconv = bb.reserve(conv_wfloats(28, 9, 1, c, c, true));
+            float *dst = bb.data.data() + m.wconv;
+            for (int tap = 0; tap < 9; ++tap)
+                for (int pl = 0; pl < 28; ++pl) {
+                    const int wch = pl < 19 ? c + pl : (pl >= 20 && pl < 20 + c ? pl - 20 : -1);
+                    if (wch < 0) continue;
+                    for (int co = 0; co < c; ++co)
+                        dst[((size_t)tap * 28 + pl) * c + co] = w[((size_t)co * (19 + c) + wch) * 9 + tap];
+                }
+            if (!fold_bn(t, "conv.bn", "conv.act", c, dst + (size_t)9 * 28 * c)) return GS_ERR_INVALID;
+        }
         if (!(w = t.get("classifier.weight", {c, c, 2, 2}))) return GS_ERR_INVALID;
         m.wclassifier = bb.push(w, (size_t)c * c * 4);
     }

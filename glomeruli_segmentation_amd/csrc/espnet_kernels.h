@@ -106,7 +106,8 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
 }
 
 // second AvgPool2d(3,2,1) of sample2.  reference: Model.py:232-239,348
-__global__ void __launch_bounds__(256) pool_kernel(const ActV in, const ActV out, int N, int C)
+__global__ void __launch_bounds__(256)
+pool_kernel(const ActV in, const ActV out, int N, int C, const float *bnp2, const ActV out2, int coff2, int C2)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)N * C * out.H * out.W)
@@ -121,7 +122,10 @@ __global__ void __launch_bounds__(256) pool_kernel(const ActV in, const ActV out
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
             s += ldz(in, n, c, 2 * y - 1 + ky, 2 * x - 1 + kx);
-    *at(out, n, c, y, x) = s / 9.0f;
+    s = s / 9.0f;
+    *at(out, n, c, y, x) = s;
+    if (bnp2)   // the inp2 slice of b2 = BR(131) over cat([output1, output1_0, inp2]) (Model.py:359)
+        *at(out2, n, coff2 + c, y, x) = bn_prelu(s, bnp2, C2, coff2 + c);
 }
 
 // b2: cat([output1, output1_0, inp2]) -> BR(131).  reference: Model.py:359 (291)
@@ -288,15 +292,12 @@ __global__ void __launch_bounds__(256) dec3_kernel(const Dec3Args a)
             }
 }
 
-// conv CBR(19+classes,classes,3) on cat([comb_l2_l3, output0_cat]) -> classifier deconv -> logits
-// -> first-max argmax -> uint8 mask -> per-class pixel counts.  One thread per 1/2-scale pixel
-// (= a 2x2 block of output pixels).
-// reference: Model.py:375-377; VisualizeResults_iou.py:128 (argmax), :151-155 (counts)
+// classifier ConvTranspose2d(classes,classes,2,2) -> logits -> first-max argmax -> uint8 mask ->
+// per-class pixel counts, on the output of conv CBR(19+classes,classes,3) (which runs on the matrix
+// cores, CFG_DEC_CONV).  One thread per 1/2-scale pixel (= a 2x2 block of output pixels).
+// reference: Model.py:377; VisualizeResults_iou.py:128 (argmax), :151-155 (counts)
 struct Dec4Args {
-    ActV e;              // comb_l2_l3 (CLS channels)
-    ActV a0;             // output0_cat (19 channels)
-    const float *wc;     // conv.conv.weight [CLS][CLS+19][3][3]
-    const float *bnc;    // conv bn+act folded [3][CLS]
+    ActV f;              // concat_features: conv CBR output, CLS channels at 1/2 scale
     const float *wcl;    // classifier.weight [CLS][CLS][2][2]
     float *logits;       // [N][CLS][H][W] or null
     unsigned char *mask; // [N][H][W] or null
@@ -308,10 +309,9 @@ template <int CLS>
 __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
 {
     __shared__ unsigned int lhist[CLS];
-    const int H1 = a.e.H, W1 = a.e.W;
+    const int H1 = a.f.H, W1 = a.f.W;
     const int H = 2 * H1, W = 2 * W1;
-    // one block never straddles two images: grid.y = image
-    const int n = blockIdx.y;
+    const int n = blockIdx.y;   // one block never straddles two images
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (a.hist) {
         if (threadIdx.x < CLS)
@@ -324,21 +324,7 @@ __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
         float s[CLS];
 #pragma unroll
         for (int k = 0; k < CLS; ++k)
-            s[k] = 0.0f;
-        for (int c = 0; c < CLS + 19; ++c)
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float v = c < CLS ? ldz(a.e, n, c, y - 1 + ky, x - 1 + kx)
-                                            : ldz(a.a0, n, c - CLS, y - 1 + ky, x - 1 + kx);
-#pragma unroll
-                    for (int k = 0; k < CLS; ++k)
-                        s[k] = fmaf(a.wc[((k * (CLS + 19) + c) * 3 + ky) * 3 + kx], v, s[k]);
-                }
-#pragma unroll
-        for (int k = 0; k < CLS; ++k)
-            s[k] = bn_prelu(s[k], a.bnc, CLS, k);
+            s[k] = *at(a.f, n, k, y, x);
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
             unsigned char m[2];
@@ -346,18 +332,23 @@ __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
             for (int dx = 0; dx < 2; ++dx) {
                 float best = 0.0f;
                 int bi = 0;
+                float lg[CLS];
 #pragma unroll
                 for (int o = 0; o < CLS; ++o) {
                     float t = 0.0f;
 #pragma unroll
                     for (int i = 0; i < CLS; ++i)
                         t = fmaf(s[i], a.wcl[((i * CLS + o) * 2 + dy) * 2 + dx], t);
-                    if (a.logits)
-                        a.logits[(((long long)n * CLS + o) * H + 2 * y + dy) * W + 2 * x + dx] = t;
+                    lg[o] = t;
                     if (o == 0 || t > best) {   // strict '>' : first maximum wins
                         best = t;
                         bi = o;
                     }
+                }
+                if (a.logits) {
+#pragma unroll
+                    for (int o = 0; o < CLS; ++o)
+                        a.logits[(((long long)n * CLS + o) * H + 2 * y + dy) * W + 2 * x + dx] = lg[o];
                 }
                 m[dx] = (unsigned char)bi;
                 if (a.hist)

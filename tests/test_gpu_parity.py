@@ -40,8 +40,9 @@ def test_stage_by_stage(torch_mod, engine1):
     """every stage boundary of the 64x128 tile against the reference's activations"""
     z = load_golden("stages_fold1.npz")
     _segment(torch_mod, engine1, z["tile"])
-    names = {"b1": "b1", "sample2": "sample2", "level2_0": "level2_0", "level2.0": "level2.0", "level2.1": "level2.1",
-             "b2": "b2", "level3_0": "level3_0", "up_l3": "up_l3", "up_l2": "up_l2"}
+    # level2.1 is only materialised through b2 (its BR is fused into the producer's epilogue)
+    names = {"b1": "b1", "sample2": "sample2", "level2_0": "level2_0", "level2.0": "level2.0",
+             "b2": "b2", "level3_0": "level3_0", "up_l3": "up_l3", "up_l2": "up_l2", "conv": "conv"}
     names.update({"level3.%d" % i: "level3.%d" % i for i in (6, 7)})   # earlier ping-pong buffers are reused
     worst = {}
     for mine, ref in names.items():
