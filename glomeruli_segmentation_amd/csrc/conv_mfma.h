@@ -74,6 +74,7 @@ struct ConvArgs {
     long long out2_sn;
     int out2_sc, out2_pitch, out2_off, out2_coff;
     unsigned out2_img_bytes;
+    int stagger;   // units of 1024 cycles by which waves WAVES/2.. start late (0 = off)
     int N, H, W;   // OUTPUT size
     int strips;    // pixel strips per output row
     int total_tasks;
@@ -86,7 +87,7 @@ constexpr int F_NOSTORE = 4; // skip the primary store (the block output is only
 constexpr int F_DUAL = 8;    // second store into a concat buffer through a second BN+PReLU: the b2 / b3
                              // "BR over a torch.cat" stages (Model.py:359) fused into the producers
 
-template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int D, int FLAGS>
+template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int G, int FLAGS>
 __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 {
     constexpr bool BNACT = FLAGS & F_BNACT, RES = FLAGS & F_RES, STORE1 = !(FLAGS & F_NOSTORE), DUAL = FLAGS & F_DUAL;
@@ -97,12 +98,17 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     constexpr int COUT = NOUT1 + (NDIL - 1) * NOUT;
     constexpr int TYN = TAPS == 9 ? 3 : 1;
     constexpr int TXN = TAPS == 9 ? 3 : 1;
-    constexpr int SPD = TYN * NSTEP * TXN;   // k-steps per dilation, order (ty, cin-group, tx): tx fastest
-    constexpr int NTOT = NDIL * SPD;
-    constexpr int NCHUNK = NTOT / D;
+    // k-steps of one dilation in the order (row group rg = ty*NSTEP + cin-group, tx): tx fastest.  A
+    // chunk is G consecutive row groups x all TXN horizontal taps = D steps, so inside a chunk the tap
+    // and slot of every step are compile-time constants and only G (ty, cin-group) pairs are decoded
+    // on the scalar unit per chunk (decoding every step cost ~40 SALU instructions per 4 MFMAs).
+    constexpr int RGN = TYN * NSTEP;          // row groups per dilation
+    constexpr int D = G * TXN;                // ring depth = steps per chunk
+    constexpr int CPD = RGN / G;              // chunks per dilation
+    constexpr int NCHUNK = NDIL * CPD;
     static_assert(CINP % KL == 0, "k-steps must tile");
     static_assert(TAPS == 1 || TAPS == 9, "1x1 or 3x3");
-    static_assert(SPD % D == 0, "ring depth must divide the steps of one dilation");
+    static_assert(RGN % G == 0, "chunk must divide the row groups of one dilation");
     static_assert(NROW <= MT, "one MFMA row block");
     constexpr int KSTR = 4;   // accumulator rows of k-group kq sit KSTR*kq above those of group 0 (both shapes)
 
@@ -122,13 +128,13 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     // Each wave takes a contiguous range of tasks; workgroups that share an XCD (equal
     // blockIdx % 8 under round-robin dispatch: speed only) take neighbouring ranges, so one XCD's
     // L2 sees a contiguous slab of images.
-    const int G = gridDim.x;
+    const int NB = gridDim.x;
     int vb = blockIdx.x;
-    if ((G & 7) == 0)
-        vb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    if ((NB & 7) == 0)
+        vb = (blockIdx.x & 7) * (NB >> 3) + (blockIdx.x >> 3);
     const long long wg = (long long)vb * WAVES + wid;
-    const int t0 = (int)((long long)a.total_tasks * wg / ((long long)G * WAVES));
-    const int t1 = (int)((long long)a.total_tasks * (wg + 1) / ((long long)G * WAVES));
+    const int t0 = (int)((long long)a.total_tasks * wg / ((long long)NB * WAVES));
+    const int t1 = (int)((long long)a.total_tasks * (wg + 1) / ((long long)NB * WAVES));
     const int tasks_per_img = a.H * a.strips;
     bool staged = false;
 
@@ -155,44 +161,43 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 
         typename M::acc_t acc[P];
 
-        // The k-loop is one flat sequence of NTOT k-steps run through a ring of D operand slots:
-        // right after the MFMAs of step i have consumed slot i % D, the slot is refilled with step
-        // i + D.  Every load therefore has D steps of MFMA work (thousands of cycles) to land, at
+        // The k-loop is one flat sequence of k-steps run through a ring of D operand slots: right
+        // after the MFMAs of a step have consumed their slot, the slot is refilled with the step D
+        // later.  Every load therefore has D steps of MFMA work (thousands of cycles) to land, at
         // the register cost of a single operand set.  (The first version waited on loads it had just
         // issued: SQ_WAIT_ANY 57 % of wave cycles, MFMA pipe 42 % busy.)  The three horizontal taps
         // of a row are consecutive steps, so two of three B loads hit lines the wave has just pulled
         // into L1.
         float aq[D], bq[D][P];
-        auto fetch_b = [&](int i, int u) {
-            const int di = i / SPD;
-            int r = i - di * SPD;
-            const int ty = r / (NSTEP * TXN);
-            r -= ty * (NSTEP * TXN);
-            const int sidx = r / TXN;
-            const int tx = r - sidx * TXN;
+        // operands of chunk c (dilation c / CPD, row groups (c % CPD)*G ..) into ring slots 0..D-1
+        auto fetch_b = [&](int c, int g, int tx) {
+            const int di = c / CPD;
+            const int rg = (c - di * CPD) * G + g;
+            const int ty = rg / NSTEP;
+            const int sidx = rg - ty * NSTEP;
             const int toff = TAPS == 9 ? ((ty - 1) * a.in_pitch + (tx - 1)) << di : 0;
             const int soff = sbase + (toff + sidx * KL * a.in_sc) * 4;
 #pragma unroll
             for (int p = 0; p < P; ++p)
-                bq[u][p] = __builtin_bit_cast(
+                bq[g * TXN + tx][p] = __builtin_bit_cast(
                     float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + p * MT * STRIDE * 4, soff, 0));
         };
-        auto fetch_a = [&](int i, int u) {
-            const int di = i / SPD;
-            int r = i - di * SPD;
-            const int ty = r / (NSTEP * TXN);
-            r -= ty * (NSTEP * TXN);
-            const int sidx = r / TXN;
-            const int tx = r - sidx * TXN;
+        auto fetch_a = [&](int c, int g, int tx) {
+            const int di = c / CPD;
+            const int rg = (c - di * CPD) * G + g;
+            const int ty = rg / NSTEP;
+            const int sidx = rg - ty * NSTEP;
             const int tap = TAPS == 9 ? ty * 3 + tx : 0;
-            aq[u] = lds[((di * TAPS + tap) * CINP + sidx * KL) * NROW + lbase];
+            aq[g * TXN + tx] = lds[((di * TAPS + tap) * CINP + sidx * KL) * NROW + lbase];
         };
 
-        // prologue: the first D steps' activations are requested before the weights are staged, so
+        // prologue: the first chunk's activations are requested before the weights are staged, so
         // their latency overlaps the LDS fill
 #pragma unroll
-        for (int u = 0; u < D; ++u)
-            fetch_b(u, u);
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int tx = 0; tx < TXN; ++tx)
+                fetch_b(0, g, tx);
         if (!staged) {
             for (int i = tid * 4; i < a.wfloats; i += WAVES * 64 * 4)
                 *reinterpret_cast<float4 *>(lds + i) = *reinterpret_cast<const float4 *>(a.wpack + i);
@@ -201,34 +206,43 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         }
         if (idle)
             break;
+        // optional stagger: the two waves that share a SIMD run the same program on equal-sized tasks
+        // and would otherwise reach their epilogues (no MFMA issue) together
+        if (a.stagger > 0 && wid >= WAVES / 2 && task == t0)
+            for (int z = 0; z < a.stagger; ++z)
+                __builtin_amdgcn_s_sleep(16);
 #pragma unroll
-        for (int u = 0; u < D; ++u)
-            fetch_a(u, u);
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int tx = 0; tx < TXN; ++tx)
+                fetch_a(0, g, tx);
 
         for (int c = 0; c < NCHUNK; ++c) {
-            const int i0 = c * D;
-            if (i0 % SPD == 0 && i0 < 2 * SPD) {   // d1 and d2 start fresh; d4, d8, d16 keep adding (HFF)
+            if (c % CPD == 0 && c < 2 * CPD) {   // d1 and d2 start fresh; d4, d8, d16 keep adding (HFF)
 #pragma unroll
                 for (int p = 0; p < P; ++p)
                     acc[p] = (typename M::acc_t)(0.0f);
             }
-            const int nx = (c + 1 < NCHUNK ? i0 + D : i0);   // the last chunk refetches itself (unused)
+            const int nx = c + 1 < NCHUNK ? c + 1 : c;   // the last chunk refetches itself (unused)
 #pragma unroll
-            for (int u = 0; u < D; ++u) {
+            for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int p = 0; p < P; ++p)
-                    acc[p] = M::run(aq[u], bq[u][p], acc[p]);
-                fetch_b(nx + u, u);
-                fetch_a(nx + u, u);
-                // pin the ring order: left alone, hipcc sinks the refill loads to the end of the
-                // chunk, which shrinks the prefetch distance from D steps to a few
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if ((i0 + D) % SPD != 0)
+                for (int tx = 0; tx < TXN; ++tx) {
+                    const int u = g * TXN + tx;
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        acc[p] = M::run(aq[u], bq[u][p], acc[p]);
+                    fetch_b(nx, g, tx);
+                    fetch_a(nx, g, tx);
+                    // pin the ring order: left alone, hipcc sinks the refill loads to the end of the
+                    // chunk, which shrinks the prefetch distance from D steps to a few
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            if ((c + 1) % CPD != 0)
                 continue;
             // last chunk of a dilation: write this branch's concat slot (the accumulator keeps
             // running for the fusion adds)
-            const int di = i0 / SPD;
+            const int di = c / CPD;
             const int nout = di == 0 ? NOUT1 : NOUT;
             const int cb = di == 0 ? 0 : NOUT1 + (di - 1) * NOUT;
             // Branch-free epilogue.  Addresses are (uniform per accumulator register, in an SGPR) +
@@ -311,10 +325,10 @@ constexpr int conv_wfloats(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT, bo
     return (n + 3) / 4 * 4;
 }
 
-template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int D, int FLAGS>
+template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int G, int FLAGS>
 gs_status launch_conv_mfma(ConvArgs a, int num_cus, hipStream_t stream)
 {
-    auto kern = conv_mfma_kernel<MT, WAVES, CINP, TAPS, STRIDE, NDIL, NOUT1, NOUT, P, D, FLAGS>;
+    auto kern = conv_mfma_kernel<MT, WAVES, CINP, TAPS, STRIDE, NDIL, NOUT1, NOUT, P, G, FLAGS>;
     a.strips = cdiv(a.W, P * MT);
     a.total_tasks = a.N * a.H * a.strips;
     a.wfloats = conv_wfloats(CINP, TAPS, NDIL, NOUT1, NOUT, FLAGS & F_BNACT, FLAGS & F_DUAL);

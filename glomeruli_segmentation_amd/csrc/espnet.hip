@@ -26,15 +26,15 @@ void set_error(const char *fmt, ...)
 
 // ------------------------------------------------------------------------------------------
 // kernel configurations (template arguments of conv_mfma_kernel); see DESIGN.md "kernels"
-//                       MT WAVES CINP TAPS STRIDE NDIL NOUT1 NOUT  P  D
-#define CFG_L2_C1S       16, 8,   20,  9,   2,     1,   12,   12,   8, 9
+//                       MT WAVES CINP TAPS STRIDE NDIL NOUT1 NOUT  P  G   (ring depth = G * taps-per-row)
+#define CFG_L2_C1S       16, 8,   20,  9,   2,     1,   12,   12,   8, 3
 #define CFG_L2_C1        16, 8,   64,  1,   1,     1,   12,   12,   8, 8
-#define CFG_L2_BR        16, 8,   12,  9,   1,     5,   16,   12,   8, 9
-#define CFG_L3_C1S       32, 8,   132, 9,   2,     1,   25,   25,   4, 11
+#define CFG_L2_BR        16, 8,   12,  9,   1,     5,   16,   12,   8, 3
+#define CFG_L3_C1S       32, 8,   132, 9,   2,     1,   25,   25,   4, 6
 #define CFG_L3_C1        32, 8,   128, 1,   1,     1,   25,   25,   4, 16
-#define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 13
-#define CFG_L3_BR_W16    32, 16,  26,  9,   1,     5,   28,   25,   2, 13
-#define CFG_DEC_CONV     16, 8,   28,  9,   1,     1,   5,    5,    8, 9
+#define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 3
+#define CFG_L3_BR_W16    32, 16,  26,  9,   1,     5,   28,   25,   2, 3
+#define CFG_DEC_CONV     16, 8,   28,  9,   1,     1,   5,    5,    8, 3
 
 enum KernelId {
     K_STEM, K_POOL, K_L2_C1S, K_L2_DOWN, K_L2_C1, K_L2_ESP, K_CAT_B2, K_L3_C1S, K_L3_DOWN, K_L3_C1, K_L3_ESP,
@@ -434,9 +434,12 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             return launch_conv_mfma<CFG_L3_C1, 0>(conv_args(m->cc[cur3], wb + m->l3[i].c1, m->r3, nullptr, n), m->num_cus, s);
         });
         L.run(K_L3_ESP, px3 * (25 * 9 * 128 * 2), [&] {
+            ConvArgs ca = conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n);
             if (m->variant == 1)
-                return launch_conv_mfma<CFG_L3_BR_W16, F_BNACT | F_RES>(conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n), m->num_cus, s);
-            return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES>(conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n), m->num_cus, s);
+                return launch_conv_mfma<CFG_L3_BR_W16, F_BNACT | F_RES>(ca, m->num_cus, s);
+            if (m->variant >= 2)
+                ca.stagger = m->variant;
+            return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES>(ca, m->num_cus, s);
         });
         cur3 = nxt;
         set_stage("level3." + std::to_string(i), m->cc[cur3], 128);
