@@ -75,6 +75,7 @@ struct ConvArgs {
     int out2_sc, out2_pitch, out2_off, out2_coff;
     unsigned out2_img_bytes;
     int stagger;   // units of 1024 cycles by which waves WAVES/2.. start late (0 = off)
+    unsigned long long *stamp;   // F_X_STAMP diagnostic builds only: [wave][8] 100 MHz timestamps
     int N, H, W;   // OUTPUT size
     int strips;    // pixel strips per output row
     int total_tasks;
@@ -84,7 +85,11 @@ struct ConvArgs {
 constexpr int F_BNACT = 1;   // folded BatchNorm + PReLU on the way out
 constexpr int F_RES = 2;     // add the residual input before BN (ESP block, Model.py:211-213)
 constexpr int F_NOSTORE = 4; // skip the primary store (the block output is only consumed through out2)
-constexpr int F_DUAL = 8;    // second store into a concat buffer through a second BN+PReLU: the b2 / b3
+constexpr int F_DUAL = 8;
+constexpr int F_X_NOLOAD = 16;  // timing experiments only (results are garbage): no activation loads in the loop
+constexpr int F_X_NOLDS = 32;   // timing experiments only: no LDS weight reads in the loop
+constexpr int F_X_NOEPI = 64;   // timing experiments only: no epilogue at all
+constexpr int F_X_STAMP = 128;  // diagnostic build: per-wave s_memrealtime stamps into a.stamp (start, staged, per-dilation, end)    // second store into a concat buffer through a second BN+PReLU: the b2 / b3
                              // "BR over a torch.cat" stages (Model.py:359) fused into the producers
 
 template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int G, int FLAGS>
@@ -114,6 +119,9 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
+    unsigned long long tstamp0 = 0;
+    if (FLAGS & F_X_STAMP)
+        tstamp0 = __builtin_amdgcn_s_memrealtime();
     const float *bnp = lds + NDIL * TAPS * CINP * NROW;   // [scale | shift | alpha][COUT]
 
     const int lane = tid & 63;
@@ -161,6 +169,38 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 
         typename M::acc_t acc[P];
 
+        // per-lane epilogue offsets: lanes beyond the row end get an offset past num_records, which the
+        // buffer range check turns into a dropped store / zero load (no exec-mask branches)
+        constexpr int OOB = 0x7ffffff0;
+        int vo[P], vr[P], vo2[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const bool xok = x0 + p * MT + px < a.W;
+            vo[p] = xok ? vout + p * MT * 4 : OOB;
+            vr[p] = xok ? vres + p * MT * 4 : OOB;
+            vo2[p] = xok ? vout2 + p * MT * 4 : OOB;
+        }
+        // The residual (block input) values of a whole concat slot live in dedicated registers and are
+        // requested a full dilation ahead of the epilogue that adds them: fetched next to the store,
+        // they cost four exposed HBM round trips per slot (measured 33 us of a 183 us launch).
+        float resv[RES ? M::NACC : 1][P];
+        auto prefetch_res = [&](int di) {
+            if (!RES)
+                return;
+            const int nout = di == 0 ? NOUT1 : NOUT;
+            const int cb = di == 0 ? 0 : NOUT1 + (di - 1) * NOUT;
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r) {
+                const int ch0 = M::row(r, 0);
+                const bool live = ch0 + kq * KSTR < nout;
+                const int sr = (cb + ch0) * a.res_sc * 4 + sres;
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    resv[RES ? r : 0][p] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(rres, live ? vr[p] : OOB, sr, 0));
+            }
+        };
+
         // The k-loop is one flat sequence of k-steps run through a ring of D operand slots: right
         // after the MFMAs of a step have consumed their slot, the slot is refilled with the step D
         // later.  Every load therefore has D steps of MFMA work (thousands of cycles) to land, at
@@ -177,6 +217,12 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
             const int sidx = rg - ty * NSTEP;
             const int toff = TAPS == 9 ? ((ty - 1) * a.in_pitch + (tx - 1)) << di : 0;
             const int soff = sbase + (toff + sidx * KL * a.in_sc) * 4;
+            if (FLAGS & F_X_NOLOAD) {
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    bq[g * TXN + tx][p] = __builtin_bit_cast(float, soff + p);
+                return;
+            }
 #pragma unroll
             for (int p = 0; p < P; ++p)
                 bq[g * TXN + tx][p] = __builtin_bit_cast(
@@ -188,6 +234,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
             const int ty = rg / NSTEP;
             const int sidx = rg - ty * NSTEP;
             const int tap = TAPS == 9 ? ty * 3 + tx : 0;
+            if (FLAGS & F_X_NOLDS) {
+                aq[g * TXN + tx] = __builtin_bit_cast(float, tap + sidx + lbase);
+                return;
+            }
             aq[g * TXN + tx] = lds[((di * TAPS + tap) * CINP + sidx * KL) * NROW + lbase];
         };
 
@@ -199,25 +249,48 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
             for (int tx = 0; tx < TXN; ++tx)
                 fetch_b(0, g, tx);
         if (!staged) {
-            for (int i = tid * 4; i < a.wfloats; i += WAVES * 64 * 4)
-                *reinterpret_cast<float4 *>(lds + i) = *reinterpret_cast<const float4 *>(a.wpack + i);
+            // weights -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR
+            // round trip), every piece in flight at once; a register-staged copy loop took 9 us of a
+            // 183 us launch here
+            const int pieces = (a.wfloats + 255) / 256;
+            for (int j = wid; j < pieces; j += WAVES)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(a.wpack + j * 256 + lane * 4),
+                    (__attribute__((address_space(3))) void *)(lds + j * 256), 16, 0, 0);
             __syncthreads();
             staged = true;
         }
         if (idle)
             break;
+        if ((FLAGS & F_X_STAMP) && lane == 0 && task == t0) {
+            a.stamp[wg * 8 + 0] = tstamp0;
+            a.stamp[wg * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+        }
         // optional stagger: the two waves that share a SIMD run the same program on equal-sized tasks
         // and would otherwise reach their epilogues (no MFMA issue) together
-        if (a.stagger > 0 && wid >= WAVES / 2 && task == t0)
-            for (int z = 0; z < a.stagger; ++z)
+        if (a.stagger > 0 && task == t0) {
+            const int ph = (blockIdx.x * 3 + wid * 5) & 7;   // 8 phases spread over waves and workgroups
+            for (int z = 0; z < a.stagger * ph; ++z)
                 __builtin_amdgcn_s_sleep(16);
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
             for (int tx = 0; tx < TXN; ++tx)
                 fetch_a(0, g, tx);
 
+        prefetch_res(0);
+
         for (int c = 0; c < NCHUNK; ++c) {
+            if (NDIL > 1 && c % CPD == 0) {
+                // The two waves of a SIMD run the same program; arbitration prefers the older one, which
+                // then finishes its task ~20 % earlier and leaves its partner alone on the pipe.
+                // Alternating static priority per dilation keeps the pair level.
+                if (((c / CPD) + (wid >= WAVES / 2 ? 1 : 0)) & 1)
+                    __builtin_amdgcn_s_setprio(1);
+                else
+                    __builtin_amdgcn_s_setprio(0);
+            }
             if (c % CPD == 0 && c < 2 * CPD) {   // d1 and d2 start fresh; d4, d8, d16 keep adding (HFF)
 #pragma unroll
                 for (int p = 0; p < P; ++p)
@@ -240,78 +313,65 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                 }
             if ((c + 1) % CPD != 0)
                 continue;
+            if (FLAGS & F_X_NOEPI) {
+                float keep = 0.0f;   // keep every accumulator register live
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int r = 0; r < M::NACC; ++r)
+                        keep += acc[p][r];
+                if (keep == 123.456f)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, keep), rout, vout, sout, 0);
+                continue;
+            }
             // last chunk of a dilation: write this branch's concat slot (the accumulator keeps
             // running for the fusion adds)
             const int di = c / CPD;
             const int nout = di == 0 ? NOUT1 : NOUT;
             const int cb = di == 0 ? 0 : NOUT1 + (di - 1) * NOUT;
-            // Branch-free epilogue.  Addresses are (uniform per accumulator register, in an SGPR) +
-            // (one per-lane offset); lanes that hold nothing to store (channel >= nout, x >= W) get
-            // an offset beyond num_records, which the buffer range check turns into a dropped store /
-            // zero load -- no exec-mask branches, so the residual loads of a register group are all
-            // in flight together (the branchy first version waited vmcnt(0) per element).
-            int vo[P], vr[P], vo2[P];
+            // Branch-free epilogue: addresses are (uniform per accumulator register, in an SGPR) + (one
+            // per-lane offset), so the whole slot is straight-line VALU + buffer stores.
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const bool xok = x0 + p * MT + px < a.W;
-                vo[p] = xok ? vout + p * MT * 4 : (int)0x7ffffff0;
-                vr[p] = xok ? vres + p * MT * 4 : (int)0x7ffffff0;
-                vo2[p] = xok ? vout2 + p * MT * 4 : (int)0x7ffffff0;
-            }
-            constexpr int RG = 4;   // accumulator registers per group
-#pragma unroll
-            for (int g = 0; g < M::NACC / RG; ++g) {
-                float resv[RG][P];
-                if (RES) {
-#pragma unroll
-                    for (int rr = 0; rr < RG; ++rr) {
-                        const int ch0 = M::row(g * RG + rr, 0);
-                        const int sr = (cb + ch0) * a.res_sc * 4 + sres;
-#pragma unroll
-                        for (int p = 0; p < P; ++p)
-                            resv[rr][p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, vr[p], sr, 0));
+            for (int r = 0; r < M::NACC; ++r) {
+                const int ch0 = M::row(r, 0);   // channel held by k-group 0; group kq holds ch0 + kq*KSTR
+                const bool live = ch0 + kq * KSTR < nout;
+                const int so = (cb + ch0) * a.out_sc * 4 + sout;
+                const int so2 = DUAL ? (a.out2_coff + cb + ch0) * a.out2_sc * 4 + sout2 : 0;
+                float scale = 1.0f, shift = 0.0f, alpha = 1.0f, scale2 = 1.0f, shift2 = 0.0f, alpha2 = 1.0f;
+                if (BNACT) {
+                    const float *bp = bnp + (live ? cb + ch0 + kq * KSTR : 0);
+                    scale = bp[0];
+                    shift = bp[COUT];
+                    alpha = bp[2 * COUT];
+                    if (DUAL) {
+                        scale2 = bp[3 * COUT];
+                        shift2 = bp[4 * COUT];
+                        alpha2 = bp[5 * COUT];
                     }
                 }
 #pragma unroll
-                for (int rr = 0; rr < RG; ++rr) {
-                    const int r = g * RG + rr;
-                    const int ch0 = M::row(r, 0);   // channel held by k-group 0; group kq holds ch0 + kq*KSTR
-                    const bool live = ch0 + kq * KSTR < nout;
-                    const int so = (cb + ch0) * a.out_sc * 4 + sout;
-                    const int so2 = DUAL ? (a.out2_coff + cb + ch0) * a.out2_sc * 4 + sout2 : 0;
-                    float scale = 1.0f, shift = 0.0f, alpha = 1.0f, scale2 = 1.0f, shift2 = 0.0f, alpha2 = 1.0f;
+                for (int p = 0; p < P; ++p) {
+                    float v = acc[p][r];
+                    if (RES)
+                        v += resv[RES ? r : 0][p];
                     if (BNACT) {
-                        const float *bp = bnp + (live ? cb + ch0 + kq * KSTR : 0);
-                        scale = bp[0];
-                        shift = bp[COUT];
-                        alpha = bp[2 * COUT];
-                        if (DUAL) {
-                            scale2 = bp[3 * COUT];
-                            shift2 = bp[4 * COUT];
-                            alpha2 = bp[5 * COUT];
-                        }
+                        v = v * scale + shift;
+                        v = v > 0.0f ? v : alpha * v;
                     }
-#pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        float v = acc[p][r];
-                        if (RES)
-                            v += resv[rr][p];
-                        if (BNACT) {
-                            v = v * scale + shift;
-                            v = v > 0.0f ? v : alpha * v;
-                        }
-                        if (STORE1)
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout,
-                                                                  live ? vo[p] : (int)0x7ffffff0, so, 0);
-                        if (DUAL) {
-                            float v2 = v * scale2 + shift2;
-                            v2 = v2 > 0.0f ? v2 : alpha2 * v2;
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2), rout2,
-                                                                  live ? vo2[p] : (int)0x7ffffff0, so2, 0);
-                        }
+                    if (STORE1)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, live ? vo[p] : OOB, so, 0);
+                    if (DUAL) {
+                        float v2 = v * scale2 + shift2;
+                        v2 = v2 > 0.0f ? v2 : alpha2 * v2;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2), rout2,
+                                                              live ? vo2[p] : OOB, so2, 0);
                     }
                 }
             }
+            if (di + 1 < NDIL)
+                prefetch_res(di + 1);
+            if ((FLAGS & F_X_STAMP) && lane == 0 && task == t0)
+                a.stamp[wg * 8 + 2 + di] = __builtin_amdgcn_s_memrealtime();
         }
     }
 }
@@ -332,7 +392,7 @@ gs_status launch_conv_mfma(ConvArgs a, int num_cus, hipStream_t stream)
     a.strips = cdiv(a.W, P * MT);
     a.total_tasks = a.N * a.H * a.strips;
     a.wfloats = conv_wfloats(CINP, TAPS, NDIL, NOUT1, NOUT, FLAGS & F_BNACT, FLAGS & F_DUAL);
-    const size_t lds_bytes = (size_t)a.wfloats * sizeof(float);
+    const size_t lds_bytes = (size_t)((a.wfloats + 255) / 256 * 256) * sizeof(float);   // whole 1-KiB DMA pieces
     static bool attr_done = false;
     if (!attr_done) {
         GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -437,8 +437,35 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             ConvArgs ca = conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n);
             if (m->variant == 1)
                 return launch_conv_mfma<CFG_L3_BR_W16, F_BNACT | F_RES>(ca, m->num_cus, s);
-            if (m->variant >= 2)
-                ca.stagger = m->variant;
+            if (m->variant >= 2 && m->variant < 100)
+                ca.stagger = m->variant - 1;
+            if (m->variant == 105) {
+                static unsigned long long *stamp = nullptr;
+                if (!stamp) hipMalloc(reinterpret_cast<void **>(&stamp), 4096 * 8 * 8);
+                hipMemsetAsync(stamp, 0, 4096 * 8 * 8, s);
+                ca.stamp = stamp;
+                gs_status st = launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_X_STAMP>(ca, m->num_cus, s);
+                if (i == m->q - 1) {
+                    std::vector<unsigned long long> h(2048 * 8);
+                    hipMemcpy(h.data(), stamp, h.size() * 8, hipMemcpyDeviceToHost);
+                    if (FILE *f = std::fopen("gpurun_out/stamps.txt", "w")) {
+                        for (int w = 0; w < 2048; ++w) {
+                            for (int k = 0; k < 7; ++k) std::fprintf(f, "%llu ", h[w * 8 + k]);
+                            std::fprintf(f, "\n");
+                        }
+                        std::fclose(f);
+                    }
+                }
+                return st;
+            }
+            if (m->variant == 101)
+                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI>(ca, m->num_cus, s);
+            if (m->variant == 102)
+                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI | F_X_NOLOAD>(ca, m->num_cus, s);
+            if (m->variant == 103)
+                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI | F_X_NOLOAD | F_X_NOLDS>(ca, m->num_cus, s);
+            if (m->variant == 104)
+                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_X_NOLOAD>(ca, m->num_cus, s);
             return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES>(ca, m->num_cus, s);
         });
         cur3 = nxt;
@@ -628,7 +655,7 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
         if (!(w = t.get("classifier.weight", {c, c, 2, 2}))) return GS_ERR_INVALID;
         m.wclassifier = bb.push(w, (size_t)c * c * 4);
     }
-    bb.reserve(64);   // tail guard for float4 staging reads
+    bb.reserve(512);   // tail guard: LDS-DMA staging reads whole 1-KiB pieces
     GS_HIP(hipMalloc(reinterpret_cast<void **>(&m.dblob), bb.data.size() * sizeof(float)));
     GS_HIP(hipMemcpy(m.dblob, bb.data.data(), bb.data.size() * sizeof(float), hipMemcpyHostToDevice));
     *out = h.release();
