@@ -15,7 +15,7 @@ LIB = os.path.join(PKG, "libglomseg.so")
 SOURCES = ["espnet.hip", "detect_ops.hip"]
 HEADERS = ["gs_internal.h", "conv_mfma.h", "espnet_kernels.h", os.path.join("..", "..", "include", "glomseg.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
-         "-Wno-unused-value"]
+         "-Wno-unused-value"] + os.environ.get("GS_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _stale():

@@ -399,12 +399,13 @@ gs_status launch_conv_mfma(ConvArgs a, int num_cus, hipStream_t stream)
                                    (int)lds_bytes));
         attr_done = true;
     }
-    // workgroups resident per CU by LDS and by wave slots (WAVES <= 8: up to 2 waves per SIMD; the
-    // 12/16-wave variants fill the CU with one workgroup)
-    int per_cu = (int)((160 * 1024) / (lds_bytes + 256));
-    if (per_cu < 1) per_cu = 1;
-    const int wave_slots = WAVES >= 8 ? 1 : 8 / WAVES;
-    if (per_cu > wave_slots) per_cu = wave_slots;
+    // resident workgroups per CU from the occupancy query (registers, LDS, wave slots), once per kernel
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int nb = 0;
+        GS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), WAVES * 64, lds_bytes));
+        per_cu = nb < 1 ? 1 : nb;
+    }
     int grid = num_cus * per_cu;
     const int need = cdiv(a.total_tasks, WAVES);
     if (grid > need) grid = need;

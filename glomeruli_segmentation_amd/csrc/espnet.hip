@@ -27,13 +27,17 @@ void set_error(const char *fmt, ...)
 // ------------------------------------------------------------------------------------------
 // kernel configurations (template arguments of conv_mfma_kernel); see DESIGN.md "kernels"
 //                       MT WAVES CINP TAPS STRIDE NDIL NOUT1 NOUT  P  G   (ring depth = G * taps-per-row)
-#define CFG_L2_C1S       16, 8,   20,  9,   2,     1,   12,   12,   8, 3
-#define CFG_L2_C1        16, 8,   64,  1,   1,     1,   12,   12,   8, 8
-#define CFG_L2_BR        16, 8,   12,  9,   1,     5,   16,   12,   8, 3
+#ifndef L2P
+#define L2P 8
+#endif
+#define CFG_L2_C1S       16, 8,   20,  9,   2,     1,   12,   12,   L2P, 3
+#define CFG_L2_C1        16, 8,   64,  1,   1,     1,   12,   12,   L2P, 8
+#define CFG_L2_BR        16, 8,   12,  9,   1,     5,   16,   12,   L2P, 3
 #define CFG_L3_C1S       32, 8,   132, 9,   2,     1,   25,   25,   4, 6
 #define CFG_L3_C1        32, 8,   128, 1,   1,     1,   25,   25,   4, 16
 #define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 3
 #define CFG_L3_BR_W16    32, 16,  26,  9,   1,     5,   28,   25,   2, 3
+#define CFG_L3_BR_P2     32, 8,   26,  9,   1,     5,   28,   25,   2, 13
 #define CFG_DEC_CONV     16, 8,   28,  9,   1,     1,   5,    5,    8, 3
 
 enum KernelId {
@@ -194,7 +198,7 @@ static Act make_act(int C, int Cp, int H, int W, int pad_t, int pad_b, int pad_l
     a.Cp = Cp;
     a.H = H;
     a.W = W;
-    a.pitch = (int)round_up(pad_l + W + pad_r, 4);
+    a.pitch = (int)round_up(pad_l + W + pad_r, 32);   // 128-byte rows: interior stores stay line-aligned
     a.sc = (pad_t + H + pad_b) * a.pitch;
     a.off = pad_t * a.pitch + pad_l;
     a.sn = (long long)Cp * a.sc;
@@ -215,14 +219,14 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
     // output0_cat (planes 0..18) shares one buffer with comb_l2_l3 (planes 20..24, written by dec3): the
     // decoder's conv CBR(19+classes, classes, 3) then reads its torch.cat input (Model.py:375) as ONE
     // 28-plane activation (planes 19 and 25..27 stay zero), with zero pad on all four sides
-    m->a0 = make_act(19, 28, H1, W1, 1, 1, 4, 4);
+    m->a0 = make_act(19, 28, H1, W1, 1, 1, 32, 1);
     m->inp1 = make_act(3, 3, H1, W1, 0, 0, 0, 0);
     m->inp2 = make_act(3, 3, H2, W2, 0, 0, 0, 0);
-    m->r2 = make_act(12, 12, H2, W2, 16, 16, 16, 16);  // dilation up to 16
+    m->r2 = make_act(12, 12, H2, W2, 16, 16, 32, 16);  // dilation up to 16
     for (int i = 0; i < 3; ++i)
         m->bb[i] = make_act(64, 64, H2, W2, 0, 0, 0, 0);
-    m->a1 = make_act(131, 132, H2, W2, 1, 0, 4, 4);
-    m->r3 = make_act(25, 26, H3, W3, 16, 16, 16, 16);
+    m->a1 = make_act(131, 132, H2, W2, 1, 0, 32, 1);
+    m->r3 = make_act(25, 26, H3, W3, 16, 16, 32, 16);
     for (int i = 0; i < 3; ++i)
         m->cc[i] = make_act(128, 128, H3, W3, 0, 0, 0, 0);
     m->o2c = make_act(cls, cls, H2, W2, 0, 0, 0, 0);
@@ -437,6 +441,8 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             ConvArgs ca = conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n);
             if (m->variant == 1)
                 return launch_conv_mfma<CFG_L3_BR_W16, F_BNACT | F_RES>(ca, m->num_cus, s);
+            if (m->variant == 0)
+                return launch_conv_mfma<CFG_L3_BR_P2, F_BNACT | F_RES>(ca, m->num_cus, s);
             if (m->variant >= 2 && m->variant < 100)
                 ca.stagger = m->variant - 1;
             if (m->variant == 105) {
@@ -458,6 +464,10 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
                 }
                 return st;
             }
+            if (m->variant == 106)   // residual loads but no stores (timing only)
+                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_NOSTORE>(ca, m->num_cus, s);
+            if (m->variant == 107)   // stores but no residual (timing only)
+                return launch_conv_mfma<CFG_L3_BR, F_BNACT>(ca, m->num_cus, s);
             if (m->variant == 101)
                 return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI>(ca, m->num_cus, s);
             if (m->variant == 102)

@@ -44,23 +44,34 @@ struct StemArgs {
     int N, H, W;             // INPUT size
 };
 
+// uint8 -> normalised fp32 goes through a 3x256 table built once per workgroup with exactly the
+// reference's three fp32 roundings (numpy: x - mean, / std, / 255; VisualizeResults_iou.py:109,111,116),
+// so it is bit-identical to computing them per pixel but costs one LDS read instead of two IEEE
+// divisions per value.
 template <bool U8>
-__device__ __forceinline__ float stem_fetch(const StemArgs &a, int n, int c, int y, int x)
+__device__ __forceinline__ float stem_fetch(const StemArgs &a, const float (*lut)[256], int n, int c, int y, int x)
 {
     if (y < 0 || y >= a.H || x < 0 || x >= a.W)
         return 0.0f;   // padding acts on the normalised tensor
-    if (U8) {
-        float v = (float)static_cast<const unsigned char *>(a.in)[(((long long)n * a.H + y) * a.W + x) * 3 + c];
-        v = v - a.mean[c];     // same three fp32 roundings as numpy (VisualizeResults_iou.py:109,111,116)
-        v = v / a.std[c];
-        return v / 255.0f;
-    }
+    if (U8)
+        return lut[c][static_cast<const unsigned char *>(a.in)[(((long long)n * a.H + y) * a.W + x) * 3 + c]];
     return static_cast<const float *>(a.in)[(((long long)n * 3 + c) * a.H + y) * a.W + x];
 }
 
 template <bool U8>
 __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
 {
+    __shared__ float lut[3][256];
+    if (U8) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = (float)threadIdx.x;
+            v = v - a.mean[c];
+            v = v / a.std[c];
+            lut[c][threadIdx.x] = v / 255.0f;
+        }
+        __syncthreads();
+    }
     const int H1 = a.H / 2, W1 = a.W / 2;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)a.N * H1 * W1)
@@ -76,7 +87,7 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
-                v[c][ky][kx] = stem_fetch<U8>(a, n, c, 2 * y - 1 + ky, 2 * x - 1 + kx);
+                v[c][ky][kx] = stem_fetch<U8>(a, lut, n, c, 2 * y - 1 + ky, 2 * x - 1 + kx);
 
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
@@ -171,6 +182,7 @@ __global__ void __launch_bounds__(256) dec1_kernel(const Dec1Args a)
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = 0.0f;
+#pragma unroll 8
     for (int c = 0; c < 256; ++c) {
         const float raw = c < 128 ? *at(a.c0, n, c, y, x) : *at(a.clast, n, c - 128, y, x);
         const float v = bn_prelu(raw, a.b3, 256, c);
@@ -226,6 +238,7 @@ __global__ void __launch_bounds__(256) dec2_kernel(const Dec2Args a)
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = 0.0f;
+#pragma unroll 8
     for (int c = 0; c < 131; ++c) {
         const float v = *at(a.a1, n, c, y, x);
 #pragma unroll
