@@ -133,20 +133,30 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     const int vres = RES ? (kq * KSTR * a.res_sc + px) * 4 : 0;
     const int vout2 = DUAL ? (kq * KSTR * a.out2_sc + px) * 4 : 0;
 
-    // Each wave takes a contiguous range of tasks; workgroups that share an XCD (equal
-    // blockIdx % 8 under round-robin dispatch: speed only) take neighbouring ranges, so one XCD's
-    // L2 sees a contiguous slab of images.
+    // Task order is (image, row, strip).  Workgroups that share an XCD (equal blockIdx % 8 under
+    // round-robin dispatch: a speed assumption only) own one contiguous eighth of the tasks, and inside
+    // it the XCD's waves sweep together: wave j takes tasks j, j + waves_per_xcd, ...  At any moment
+    // the waves of one XCD therefore work on neighbouring rows of the same image(s), so the taps
+    // they share stay in that XCD's 4 MiB L2 (with one contiguous range per wave every image of the
+    // eighth was live at once and half of the B-operand L2 requests went on to the Infinity Cache).
     const int NB = gridDim.x;
-    int vb = blockIdx.x;
-    if ((NB & 7) == 0)
-        vb = (blockIdx.x & 7) * (NB >> 3) + (blockIdx.x >> 3);
-    const long long wg = (long long)vb * WAVES + wid;
-    const int t0 = (int)((long long)a.total_tasks * wg / ((long long)NB * WAVES));
-    const int t1 = (int)((long long)a.total_tasks * (wg + 1) / ((long long)NB * WAVES));
+    int t0, t1, tstride;
+    if ((NB & 7) == 0) {
+        const int xcd = blockIdx.x & 7, per = NB >> 3;
+        const int c0 = (int)((long long)a.total_tasks * xcd / 8), c1 = (int)((long long)a.total_tasks * (xcd + 1) / 8);
+        t0 = c0 + (blockIdx.x >> 3) * WAVES + wid;
+        t1 = c1;
+        tstride = per * WAVES;
+    } else {
+        t0 = blockIdx.x * WAVES + wid;
+        t1 = a.total_tasks;
+        tstride = NB * WAVES;
+    }
+    const long long wg = (long long)blockIdx.x * WAVES + wid;   // global wave id (diagnostic stamps)
     const int tasks_per_img = a.H * a.strips;
     bool staged = false;
 
-    for (int task = t0; task < t1 || !staged; ++task) {
+    for (int task = t0; task < t1 || !staged; task += tstride) {
         const bool idle = task >= t1;   // a wave without work still has to help stage the weights
         const int tk = idle ? (a.total_tasks - 1) : task;
         const int n = tk / tasks_per_img;
