@@ -18,10 +18,15 @@ __device__ __forceinline__ float *at(const ActV &t, int n, int c, int y, int x)
 {
     return t.base + (long long)n * t.sn + (long long)c * t.sc + t.off + y * t.pitch + x;
 }
-// zero-padding read (conv / pool padding semantics)
+// zero-padding read (conv / pool padding semantics).  Branch-free on purpose: the coordinate is
+// clamped, the load is unconditional and the result is selected afterwards, so a thread's taps are
+// all in flight together (a branch per tap made hipcc wait vmcnt(0) after every load).
 __device__ __forceinline__ float ldz(const ActV &t, int n, int c, int y, int x)
 {
-    return (y >= 0 && y < t.H && x >= 0 && x < t.W) ? *at(t, n, c, y, x) : 0.0f;
+    const bool ok = (unsigned)y < (unsigned)t.H && (unsigned)x < (unsigned)t.W;
+    const int yc = min(max(y, 0), t.H - 1), xc = min(max(x, 0), t.W - 1);
+    const float v = *at(t, n, c, yc, xc);
+    return ok ? v : 0.0f;
 }
 __device__ __forceinline__ float bn_prelu(float v, const float *bnp, int C, int c)
 {
@@ -51,11 +56,15 @@ struct StemArgs {
 template <bool U8>
 __device__ __forceinline__ float stem_fetch(const StemArgs &a, const float (*lut)[256], int n, int c, int y, int x)
 {
-    if (y < 0 || y >= a.H || x < 0 || x >= a.W)
-        return 0.0f;   // padding acts on the normalised tensor
+    // branch-free (see ldz): clamp, load, select; padding acts on the normalised tensor
+    const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+    const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
+    float v;
     if (U8)
-        return lut[c][static_cast<const unsigned char *>(a.in)[(((long long)n * a.H + y) * a.W + x) * 3 + c]];
-    return static_cast<const float *>(a.in)[(((long long)n * 3 + c) * a.H + y) * a.W + x];
+        v = lut[c][static_cast<const unsigned char *>(a.in)[(((long long)n * a.H + yc) * a.W + xc) * 3 + c]];
+    else
+        v = static_cast<const float *>(a.in)[(((long long)n * 3 + c) * a.H + yc) * a.W + xc];
+    return ok ? v : 0.0f;
 }
 
 template <bool U8>
@@ -89,6 +98,9 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
             for (int kx = 0; kx < 3; ++kx)
                 v[c][ky][kx] = stem_fetch<U8>(a, lut, n, c, 2 * y - 1 + ky, 2 * x - 1 + kx);
 
+    // all arithmetic first, all stores last: a store between two weight reads would force hipcc to
+    // re-read the (possibly aliasing) weights from memory with vector loads and a full wait each time
+    float outv[19], poolv[3];
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
         float s = 0.0f;
@@ -100,7 +112,7 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
                 for (int kx = 0; kx < 3; ++kx)
                     s = fmaf(a.w1[((o * 3 + c) * 3 + ky) * 3 + kx], v[c][ky][kx], s);
         s = bn_prelu(s, a.bn1, 16, o);
-        *at(a.a0, n, o, y, x) = bn_prelu(s, a.b1, 19, o);
+        outv[o] = bn_prelu(s, a.b1, 19, o);
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -111,9 +123,15 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
             for (int kx = 0; kx < 3; ++kx)
                 s += v[c][ky][kx];
         s = s / 9.0f;   // count_include_pad=True
-        *at(a.inp1, n, c, y, x) = s;
-        *at(a.a0, n, 16 + c, y, x) = bn_prelu(s, a.b1, 19, 16 + c);
+        poolv[c] = s;
+        outv[16 + c] = bn_prelu(s, a.b1, 19, 16 + c);
     }
+#pragma unroll
+    for (int o = 0; o < 19; ++o)
+        *at(a.a0, n, o, y, x) = outv[o];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        *at(a.inp1, n, c, y, x) = poolv[c];
 }
 
 // second AvgPool2d(3,2,1) of sample2.  reference: Model.py:232-239,348
@@ -199,6 +217,7 @@ __global__ void __launch_bounds__(256) dec1_kernel(const Dec1Args a)
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = s[k] * a.br[k] + a.br[CLS + k];
+    float up[CLS][2][2];   // arithmetic first, stores last (see stem_kernel)
 #pragma unroll
     for (int o = 0; o < CLS; ++o)
 #pragma unroll
@@ -209,8 +228,13 @@ __global__ void __launch_bounds__(256) dec1_kernel(const Dec1Args a)
 #pragma unroll
                 for (int i = 0; i < CLS; ++i)
                     t = fmaf(s[i], a.wup[((i * CLS + o) * 2 + dy) * 2 + dx], t);
-                *at(a.out, n, o, 2 * y + dy, 2 * x + dx) = t;
+                up[o][dy][dx] = t;
             }
+#pragma unroll
+    for (int o = 0; o < CLS; ++o)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+            *reinterpret_cast<float2 *>(at(a.out, n, o, 2 * y + dy, 2 * x)) = make_float2(up[o][dy][0], up[o][dy][1]);
 }
 
 // level3_C 1x1 on output1_cat, cat with output2_c, BR(2*classes).  One thread per 1/4-scale pixel.
@@ -245,11 +269,15 @@ __global__ void __launch_bounds__(256) dec2_kernel(const Dec2Args a)
         for (int k = 0; k < CLS; ++k)
             s[k] = fmaf(a.w3c[k * 131 + c], v, s[k]);
     }
+    float tv[2 * CLS];
 #pragma unroll
     for (int k = 0; k < CLS; ++k) {
-        *at(a.t, n, k, y, x) = bn_prelu(s[k], a.br, 2 * CLS, k);
-        *at(a.t, n, CLS + k, y, x) = bn_prelu(*at(a.o2c, n, k, y, x), a.br, 2 * CLS, CLS + k);
+        tv[k] = bn_prelu(s[k], a.br, 2 * CLS, k);
+        tv[CLS + k] = bn_prelu(*at(a.o2c, n, k, y, x), a.br, 2 * CLS, CLS + k);
     }
+#pragma unroll
+    for (int k = 0; k < 2 * CLS; ++k)
+        *at(a.t, n, k, y, x) = tv[k];
 }
 
 // combine_l2_l3[1] CBR(2*classes,classes,3) -> up_l2 deconv -> BR(classes).  One thread per
@@ -291,6 +319,7 @@ __global__ void __launch_bounds__(256) dec3_kernel(const Dec3Args a)
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = bn_prelu(s[k], a.bnc, CLS, k);
+    float up[CLS][2][2];
 #pragma unroll
     for (int o = 0; o < CLS; ++o)
 #pragma unroll
@@ -301,8 +330,13 @@ __global__ void __launch_bounds__(256) dec3_kernel(const Dec3Args a)
 #pragma unroll
                 for (int i = 0; i < CLS; ++i)
                     t = fmaf(s[i], a.wup[((i * CLS + o) * 2 + dy) * 2 + dx], t);
-                *at(a.e, n, o, 2 * y + dy, 2 * x + dx) = bn_prelu(t, a.bnu, CLS, o);
+                up[o][dy][dx] = bn_prelu(t, a.bnu, CLS, o);
             }
+#pragma unroll
+    for (int o = 0; o < CLS; ++o)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+            *reinterpret_cast<float2 *>(at(a.e, n, o, 2 * y + dy, 2 * x)) = make_float2(up[o][dy][0], up[o][dy][1]);
 }
 
 // classifier ConvTranspose2d(classes,classes,2,2) -> logits -> first-max argmax -> uint8 mask ->
