@@ -487,8 +487,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         Dec1Args a{};
         a.c0 = view(m->cc[0]);
         a.clast = view(m->cc[cur3]);
-        a.b3 = wb + m->b3;
-        a.wcls = wb + m->wcls;
+        a.b3w = wb + m->b3;
         a.br = m->encoder_only ? nullptr : wb + m->br;
         a.wup = m->encoder_only ? nullptr : wb + m->wup3;
         a.out = view(m->o2c);
@@ -627,16 +626,28 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
     for (int i = 0; i < q; ++i)
         if (!pack_block(t, bb, e + "level3." + std::to_string(i), false, 3, m.l3[i])) return GS_ERR_INVALID;
     if (!fold_bn(t, e + "b3.bn", e + "b3.act", 256, tmp.data())) return GS_ERR_INVALID;
-    m.b3 = bb.push(tmp.data(), 768);
     if (!(w = t.get(e + "classifier.conv.weight", {c, 256, 1, 1}))) return GS_ERR_INVALID;
-    m.wcls = bb.push(w, (size_t)c * 256);
+    {
+        std::vector<float> pk(256 * 8, 0.0f);   // [channel][scale, shift, alpha, w0..w4]
+        for (int ch = 0; ch < 256; ++ch) {
+            for (int j = 0; j < 3; ++j) pk[ch * 8 + j] = tmp[j * 256 + ch];
+            for (int k = 0; k < c; ++k) pk[ch * 8 + 3 + k] = w[k * 256 + ch];
+        }
+        m.b3 = bb.push(pk.data(), pk.size());
+        m.wcls = m.b3;
+    }
     if (!m.encoder_only) {
         if (!fold_bn(t, "br", "", c, tmp.data(), false)) return GS_ERR_INVALID;
         m.br = bb.push(tmp.data(), 2 * c);
         if (!(w = t.get("up_l3.0.weight", {c, c, 2, 2}))) return GS_ERR_INVALID;
         m.wup3 = bb.push(w, (size_t)c * c * 4);
         if (!(w = t.get("level3_C.conv.weight", {c, 131, 1, 1}))) return GS_ERR_INVALID;
-        m.w3c = bb.push(w, (size_t)c * 131);
+        {
+            std::vector<float> pk(131 * 8, 0.0f);
+            for (int ch = 0; ch < 131; ++ch)
+                for (int k = 0; k < c; ++k) pk[ch * 8 + k] = w[k * 131 + ch];
+            m.w3c = bb.push(pk.data(), pk.size());
+        }
         if (!fold_bn(t, "combine_l2_l3.0.bn", "combine_l2_l3.0.act", 2 * c, tmp.data())) return GS_ERR_INVALID;
         m.cbr0 = bb.push(tmp.data(), 6 * c);
         if (!(w = t.get("combine_l2_l3.1.conv.weight", {c, 2 * c, 3, 3}))) return GS_ERR_INVALID;

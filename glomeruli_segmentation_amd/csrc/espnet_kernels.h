@@ -177,8 +177,7 @@ cat_b2_kernel(const ActV o1, const ActV o10, const ActV inp2, const float *bnp, 
 // br = BatchNorm2d(classes); up_l3 = ConvTranspose2d(classes,classes,2,stride=2)).
 struct Dec1Args {
     ActV c0, clast;      // output2_0, output2 (128 channels each)
-    const float *b3;     // folded [3][256]
-    const float *wcls;   // encoder.classifier.conv.weight [CLS][256]
+    const float *b3w;    // [256][8]: folded b3 {scale, shift, alpha} + encoder.classifier.conv.weight[0..CLS)[c]
     const float *br;     // folded br scale/shift [2][CLS]
     const float *wup;    // up_l3.0.weight [CLS][CLS][2][2]
     ActV out;            // output2_c: CLS channels at 1/4 scale
@@ -200,13 +199,18 @@ __global__ void __launch_bounds__(256) dec1_kernel(const Dec1Args a)
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = 0.0f;
+    // output2_0 and output2 share one layout (both are level-3 ping-pong buffers)
+    const long long pix = (long long)n * a.c0.sn + a.c0.off + y * a.c0.pitch + x;
 #pragma unroll 8
     for (int c = 0; c < 256; ++c) {
-        const float raw = c < 128 ? *at(a.c0, n, c, y, x) : *at(a.clast, n, c - 128, y, x);
-        const float v = bn_prelu(raw, a.b3, 256, c);
+        // per-channel constants packed [c][8] = {scale, shift, alpha, w[0..CLS)}: one scalar load per channel
+        const float *pc = a.b3w + c * 8;
+        const float raw = (c < 128 ? a.c0.base : a.clast.base)[pix + (long long)(c & 127) * a.c0.sc];
+        float v = raw * pc[0] + pc[1];
+        v = v > 0.0f ? v : pc[2] * v;
 #pragma unroll
         for (int k = 0; k < CLS; ++k)
-            s[k] = fmaf(a.wcls[k * 256 + c], v, s[k]);
+            s[k] = fmaf(pc[3 + k], v, s[k]);
     }
     if (a.enc_logits) {
 #pragma unroll
@@ -242,7 +246,7 @@ __global__ void __launch_bounds__(256) dec1_kernel(const Dec1Args a)
 struct Dec2Args {
     ActV a1;             // output1_cat (131 channels)
     ActV o2c;            // output2_c (CLS)
-    const float *w3c;    // level3_C.conv.weight [CLS][131]
+    const float *w3c;    // level3_C.conv.weight packed [131][8] (first CLS of each row used)
     const float *br;     // combine_l2_l3.0 folded [3][2*CLS]
     ActV t;              // out: 2*CLS channels
     int N;
@@ -265,9 +269,10 @@ __global__ void __launch_bounds__(256) dec2_kernel(const Dec2Args a)
 #pragma unroll 8
     for (int c = 0; c < 131; ++c) {
         const float v = *at(a.a1, n, c, y, x);
+        const float *pc = a.w3c + c * 8;   // level3_C weights packed [c][8]: one scalar load per channel
 #pragma unroll
         for (int k = 0; k < CLS; ++k)
-            s[k] = fmaf(a.w3c[k * 131 + c], v, s[k]);
+            s[k] = fmaf(pc[k], v, s[k]);
     }
     float tv[2 * CLS];
 #pragma unroll
@@ -365,6 +370,7 @@ __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
             lhist[threadIdx.x] = 0;
         __syncthreads();
     }
+    int cls_of[4] = {-1, -1, -1, -1};   // class of this thread's four output pixels (-1: thread idle)
     if (idx < H1 * W1) {
         const int x = idx % W1;
         const int y = idx / W1;
@@ -398,14 +404,24 @@ __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
                         a.logits[(((long long)n * CLS + o) * H + 2 * y + dy) * W + 2 * x + dx] = lg[o];
                 }
                 m[dx] = (unsigned char)bi;
-                if (a.hist)
-                    atomicAdd(&lhist[bi], 1u);
+                cls_of[dy * 2 + dx] = bi;
             }
             if (a.mask)
                 *reinterpret_cast<uchar2 *>(a.mask + ((long long)n * H + 2 * y + dy) * W + 2 * x) = make_uchar2(m[0], m[1]);
         }
     }
     if (a.hist) {
+        // per-class counts by wave ballot + popcount: one LDS atomic per class per wave (a per-pixel
+        // LDS atomic on five hot words serialised the whole workgroup)
+#pragma unroll
+        for (int k = 0; k < CLS; ++k) {
+            unsigned cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                cnt += (unsigned)__popcll(__ballot(cls_of[j] == k));
+            if ((threadIdx.x & 63) == 0 && cnt)
+                atomicAdd(&lhist[k], cnt);
+        }
         __syncthreads();
         if (threadIdx.x < CLS && lhist[threadIdx.x])
             atomicAdd(&a.hist[(long long)n * CLS + threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
