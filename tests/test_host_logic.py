@@ -234,3 +234,39 @@ def test_detector_scan_shards_by_window_range():
     assert parts == whole and len(whole) == plan.x_split_times * plan.y_split_times
     a = detect.build_parser().parse_args([])
     assert (a.data_category, a.conf_threshold, a.model_name, a.output_file_ext) == ("OPT_PAM", 0.6, "frozen_inference_graph.pb", "_GlomusList")
+
+
+def test_merge_matches_reference_golden():
+    """greedy merge of overlapping detections vs the reference's own class on 19 golden cases"""
+    from glomeruli_segmentation_amd import merge
+    z = load_golden("merge.npz")
+    total_in = total_out = 0
+    for i in range(int(z["n_cases"])):
+        mpp, thr = z["par_%d" % i]
+        got = merge.merge_detections(z["in_%d" % i], mpp, mpp, thr)
+        got = np.array([r[:5] for r in got], dtype=np.float64).reshape(-1, 5)
+        assert got.shape == z["out_%d" % i].shape, i
+        assert np.array_equal(got, z["out_%d" % i]), i        # same boxes, same order, bit for bit
+        total_in += len(z["in_%d" % i])
+        total_out += len(got)
+    assert total_out < total_in
+
+
+def test_merge_csv_contracts(tmp_path):
+    from glomeruli_segmentation_amd import detect, merge
+    import datetime
+    now = datetime.datetime(2020, 1, 2, 3, 4, 5)
+    rows = detect.csv_rows([[100, 200, 300, 400, 0.9], [110, 190, 310, 410, 0.8]], 8000, 16000, 8.0, "site", "PAS 001", "PAS-001.ndpi", now)
+    rows += detect.csv_rows([[0, 0, 50, 50, 0.95]], 0, 0, 8.0, "site", "PAS 002", "PAS-002.ndpi", now)
+    det = tmp_path / "det.csv"
+    det.write_text("".join(rows))
+    groups = merge.read_detections_csv(str(det))
+    assert [g[2] for g in groups] == ["PAS-001.ndpi", "PAS-002.ndpi"] and groups[0][3][0] == [8800.0, 17600.0, 10400.0, 19200.0, 0.9]
+    out = tmp_path / "merged.csv"
+    merge.merge_csv(str(det), str(out), lambda s, f: (0.2277, 0.2277), 0.35)
+    text = out.read_text().splitlines()
+    assert text[0] == 'site,PAS 001,"PAS-001.ndpi",8800,17520,10480,19280,0.9'      # the two windows' boxes merged
+    assert text[1] == 'site,PAS 002,"PAS-002.ndpi",0,0,400,400,0.95'
+    lists, order = merge.read_merged_csv(str(out))
+    assert order == ["PAS001", "PAS002"] and lists["PAS001"][0] == [8800, 17520, 10480, 19280, 0.9]
+    assert merge.crop_name(lists["PAS001"][0]) == "xmin1100_ymin2190_xmax1310_ymax2410"
