@@ -48,6 +48,8 @@ PROTOTYPES = {
     "gs_espnet_read_stage": (_I, [_P, ctypes.c_char_p, _I, _P, ctypes.c_size_t, ctypes.POINTER(_I * 3)]),
     "gs_espnet_profile_enable": (_I, [_P, _I]),
     "gs_espnet_profile_read": (_I, [_P, ctypes.POINTER(KernelTime), _I, ctypes.POINTER(_I)]),
+    "gs_crop_preprocess": (_I, [_P, _I, _I, _FP, _FP, _I, _I, _P, _P]),
+    "gs_mask_resize_nearest": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "gs_conv2d_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P]),
     "gs_roialign": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "gs_nms": (_I, [_P, _P, _I, ctypes.c_float, ctypes.c_float, _I, _P, _P, _P]),

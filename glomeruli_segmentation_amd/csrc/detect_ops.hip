@@ -201,11 +201,101 @@ nms_scan_kernel(const unsigned long long *mask, const int *order, const int *n_v
         *n_keep = kept;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Crop stage.  cv2.resize INTER_LINEAR on a float image: fx = (float)((dx+0.5)*scale-0.5),
+// sx = floor(fx), fx -= sx, clamped at both borders; horizontal pass first, then vertical.
+__device__ __forceinline__ void linear_tap(int d, double scale, int n, int &i0, int &i1, float &w1)
+{
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) {
+        s = 0;
+        f = 0.0f;
+    }
+    if (s >= n - 1) {
+        s = n - 1;
+        f = 0.0f;
+    }
+    i0 = s;
+    i1 = s + 1 < n ? s + 1 : n - 1;
+    w1 = f;
+}
+
+struct CropArgs {
+    const unsigned char *src;
+    int h, w, oh, ow;
+    float mean[3], std[3];
+    float *out;
+};
+
+__global__ void __launch_bounds__(256) crop_preprocess_kernel(const CropArgs a)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.oh * a.ow)
+        return;
+    const int ox = idx % a.ow, oy = idx / a.ow;
+    int x0, x1, y0, y1;
+    float wx, wy;
+    linear_tap(ox, (double)a.w / (double)a.ow, a.w, x0, x1, wx);
+    linear_tap(oy, (double)a.h / (double)a.oh, a.h, y0, y1, wy);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        auto norm = [&](int y, int x) {
+            float v = (float)a.src[((long long)y * a.w + x) * 3 + c];
+            v = v - a.mean[c];
+            return v / a.std[c];
+        };
+        const float top = norm(y0, x0) * (1.0f - wx) + norm(y0, x1) * wx;
+        const float bot = norm(y1, x0) * (1.0f - wx) + norm(y1, x1) * wx;
+        const float v = top * (1.0f - wy) + bot * wy;
+        a.out[((long long)c * a.oh + oy) * a.ow + ox] = v / 255.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+mask_nearest_kernel(const unsigned char *src, int h, int w, int oh, int ow, unsigned char *out)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= oh * ow)
+        return;
+    const int ox = idx % ow, oy = idx / ow;
+    int sx = (int)floor((double)ox * ((double)w / (double)ow));
+    int sy = (int)floor((double)oy * ((double)h / (double)oh));
+    sx = sx < w - 1 ? sx : w - 1;
+    sy = sy < h - 1 ? sy : h - 1;
+    out[idx] = src[(long long)sy * w + sx];
+}
+
 }  // namespace gs
 
 using namespace gs;
 
 extern "C" {
+
+gs_status gs_crop_preprocess(const uint8_t *crop_bgr, int h, int w, const float mean[3], const float std[3], int out_h,
+                             int out_w, float *out_chw, void *hip_stream)
+{
+    GS_REQUIRE(crop_bgr && mean && std && out_chw, "gs_crop_preprocess: null pointer");
+    GS_REQUIRE(h > 0 && w > 0 && out_h > 0 && out_w > 0, "gs_crop_preprocess: bad size");
+    CropArgs a{crop_bgr, h, w, out_h, out_w, {mean[0], mean[1], mean[2]}, {std[0], std[1], std[2]}, out_chw};
+    for (int i = 0; i < 3; ++i)
+        GS_REQUIRE(std[i] != 0.0f, "std[%d] is zero", i);
+    hipLaunchKernelGGL(crop_preprocess_kernel, dim3((out_h * out_w + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(hip_stream), a);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+gs_status gs_mask_resize_nearest(const uint8_t *mask, int h, int w, int out_h, int out_w, uint8_t *out, void *hip_stream)
+{
+    GS_REQUIRE(mask && out, "gs_mask_resize_nearest: null pointer");
+    GS_REQUIRE(h > 0 && w > 0 && out_h > 0 && out_w > 0, "gs_mask_resize_nearest: bad size");
+    hipLaunchKernelGGL(mask_nearest_kernel, dim3((out_h * out_w + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(hip_stream), mask, h, w, out_h, out_w, out);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
 
 gs_status gs_conv2d_nhwc(const float *in, int n, int h, int w, int cin, const float *weight, int kh, int kw, int cout,
                          const float *bias_or_null, int stride, int pad, int relu, float *out, void *hip_stream)

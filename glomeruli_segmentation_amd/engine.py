@@ -157,6 +157,31 @@ class EspnetEngine:
                  "flops_per_tile": arr[i].flops_per_tile} for i in range(n.value)]
 
 
+def crop_preprocess(crop_u8, mean, std, out_h, out_w, out=None):
+    """uint8 BGR crop [h,w,3] on the GPU -> normalised, bilinearly resized fp32 [3,out_h,out_w]
+    (VisualizeResults_iou.py:107-116 for a crop that is not network-sized)."""
+    lib = _lib.load()
+    crop_u8 = crop_u8.contiguous()
+    h, w, _ = crop_u8.shape
+    if out is None:
+        out = torch.empty((3, out_h, out_w), dtype=torch.float32, device=crop_u8.device)
+    with torch.cuda.device(crop_u8.device):
+        _lib.check(lib.gs_crop_preprocess(crop_u8.data_ptr(), h, w, _lib.fptr3(mean), _lib.fptr3(std), out_h, out_w,
+                                          out.data_ptr(), _stream_ptr(crop_u8.device)))
+    return out
+
+
+def mask_resize_nearest(mask, out_h, out_w):
+    """uint8 class map [h,w] on the GPU -> [out_h,out_w], cv2.INTER_NEAREST sampling (:129)."""
+    lib = _lib.load()
+    mask = mask.contiguous()
+    h, w = mask.shape
+    out = torch.empty((out_h, out_w), dtype=torch.uint8, device=mask.device)
+    with torch.cuda.device(mask.device):
+        _lib.check(lib.gs_mask_resize_nearest(mask.data_ptr(), h, w, out_h, out_w, out.data_ptr(), _stream_ptr(mask.device)))
+    return out
+
+
 def ensemble_segment(engines, tiles_u8, mean_stds):
     """cfg 5: mean over models of softmax(logits_k) (each model with its own mean/std) -> argmax mask,
     per-class counts.  The reference has no ensemble code; the definition is this build's."""

@@ -28,9 +28,9 @@ def imwrite_bgr(path, bgr):
 
 def _linear_taps(dst, src):
     scale = src / float(dst)
-    f = (np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5      # half-pixel centres, no antialias
+    f = ((np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)   # half-pixel centres, no antialias
     i0 = np.floor(f).astype(np.int64)
-    w1 = (f - i0).astype(np.float32)
+    w1 = f - i0.astype(np.float32)
     lo = i0 < 0
     i0[lo] = 0
     w1[lo] = 0.0
@@ -48,8 +48,9 @@ def resize_linear_f32(img, width, height):
         return img.copy()
     x0, x1, wx = _linear_taps(width, w)
     y0, y1, wy = _linear_taps(height, h)
-    rows = img[:, x0] * (1.0 - wx)[None, :, None] + img[:, x1] * wx[None, :, None]   # horizontal pass first
-    out = rows[y0] * (1.0 - wy)[:, None, None] + rows[y1] * wy[:, None, None]
+    one = np.float32(1.0)
+    rows = img[:, x0] * (one - wx)[None, :, None] + img[:, x1] * wx[None, :, None]   # horizontal pass first
+    out = rows[y0] * (one - wy)[:, None, None] + rows[y1] * wy[:, None, None]
     return out.astype(np.float32)
 
 

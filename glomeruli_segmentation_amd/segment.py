@@ -86,14 +86,16 @@ def segment_images(engine, images, mean, std, width, height, batch):
         mask = mask.cpu().numpy()
         for j, i in enumerate(idx):
             out[i] = mask[j]
+    from .engine import crop_preprocess, mask_resize_nearest
     for s in range(0, len(other), batch):
         idx = other[s:s + batch]
-        x = np.stack([imageops.normalise_then_resize(images[i], mean, std, width, height) for i in idx])
-        logits = engine.forward_logits(torch.from_numpy(x).to(engine.device))
-        cls = logits.max(1)[1].byte().cpu().numpy()          # :128
+        x = torch.empty((len(idx), 3, height, width), dtype=torch.float32, device=engine.device)
+        for j, i in enumerate(idx):      # crop stage on the GPU: normalise + bilinear resize fused (:107-116)
+            crop_preprocess(torch.from_numpy(images[i]).to(engine.device), mean, std, height, width, out=x[j])
+        cls = engine.forward_logits(x).max(1)[1].byte()       # :128
         for j, i in enumerate(idx):
             h, w = images[i].shape[:2]
-            out[i] = imageops.resize_nearest(cls[j], w, h)    # :129
+            out[i] = mask_resize_nearest(cls[j], h, w).cpu().numpy()    # :129
     return out
 
 

@@ -86,6 +86,17 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
                                  const float mean[3], const float std[3], int batch, uint8_t *masks,
                                  unsigned long long *hist);
 
+/* Crop stage either side of the forward for crops that are not already network-sized
+ * (VisualizeResults_iou.py:107-116 and :129).  gs_crop_preprocess: uint8 BGR crop [h,w,3] (device) ->
+ * normalise at crop resolution ((x-mean)/std), cv2.resize INTER_LINEAR sampling (half-pixel centres, no
+ * antialias, horizontal pass first) to out_h x out_w, then /255, written as fp32 CHW -- the tensor
+ * gs_espnet_forward(GS_IN_F32_NCHW) takes.  gs_mask_resize_nearest: cv2.resize INTER_NEAREST of a uint8
+ * class map back to the crop size (src = min(floor(dst * src_size / dst_size), src_size - 1)). */
+gs_status gs_crop_preprocess(const uint8_t *crop_bgr, int h, int w, const float mean[3], const float std[3],
+                             int out_h, int out_w, float *out_chw, void *hip_stream);
+gs_status gs_mask_resize_nearest(const uint8_t *mask, int h, int w, int out_h, int out_w, uint8_t *out,
+                                 void *hip_stream);
+
 /* 5-fold style ensemble (BASELINE cfg 5; definition in DESIGN.md): probability = mean over
  * models of softmax(logits_k), each model with its own mean/std; writes argmax mask. */
 gs_status gs_espnet_ensemble_forward(gs_espnet *const *models, int n_models, const void *in_u8, int n,
