@@ -1,0 +1,67 @@
+"""WSI mask compositor on the GPU: the consumer of the per-crop masks.
+
+Restates what module/espnet/test/eval_wsi_segmentation.py does with them -- paste every crop's class
+map onto the slide grid with max-compositing (overlay, :243-316), reduce to 1/8 scale
+(generate_whole_img, :229), colour + blend over the slide (:230-240) and accumulate a WSI-level
+confusion matrix (IOUEval.py:19-21) -- as three device kernels behind the C ABI.
+
+Definition used for the 1/8 map: pixel (X, Y) = class at level-0 pixel (8X, 8Y).  That is exactly
+what the reference's INTER_NEAREST of a full 2400-px window produces; it deviates only in the
+reference's partial edge windows, some of which the reference skips through a typo
+(`ymax > slide_width`, :386).  Crop JSON decoding (the reference stores the original RGB crop in
+imageData) is replaced by taking the class maps directly.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, imageops
+
+MAGNIFICATION = 8
+
+
+def _sp(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class SlideCompositor:
+    def __init__(self, slide_width, slide_height, device, ds=MAGNIFICATION):
+        self.lib = _lib.load()
+        self.ds = ds
+        self.device = torch.device(device)
+        self.map = torch.zeros((int(slide_height / ds), int(slide_width / ds)), dtype=torch.uint8, device=self.device)   # :371
+        self.palette = torch.from_numpy(np.ascontiguousarray(imageops.PALETTE)).to(self.device)
+
+    def paste(self, crop_mask, x1, y1):
+        """crop_mask: uint8 [h,w] (level-0 resolution) on the GPU or host; (x1,y1) level-0 origin of the box."""
+        if not isinstance(crop_mask, torch.Tensor):
+            crop_mask = torch.from_numpy(np.ascontiguousarray(crop_mask))
+        crop_mask = crop_mask.to(self.device).contiguous()
+        h, w = crop_mask.shape
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gs_wsi_paste_max(self.map.data_ptr(), self.map.shape[0], self.map.shape[1], self.ds,
+                                                 crop_mask.data_ptr(), h, w, int(x1), int(y1), _sp(self.device)))
+
+    def overlay(self, slide_bgr_small, wa=0.4, wb=0.6):
+        """slide_bgr_small: uint8 [map_h,map_w,3] BGR (the 1/8-scale slide) -> blended prediction image."""
+        img = slide_bgr_small if isinstance(slide_bgr_small, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(slide_bgr_small))
+        img = img.to(self.device).contiguous()
+        out = torch.empty_like(img)
+        h, w = self.map.shape
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gs_overlay_classmap(img.data_ptr(), self.map.data_ptr(), h, w, self.palette.data_ptr(),
+                                                    self.palette.shape[0], ctypes.c_float(wa), ctypes.c_float(wb),
+                                                    out.data_ptr(), _sp(self.device)))
+        return out
+
+    def confusion(self, gt_map, classes=5, hist=None):
+        """accumulate fast_hist(gt, pred) over the slide map; returns int64 [classes,classes] tensor."""
+        gt = gt_map if isinstance(gt_map, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(gt_map))
+        gt = gt.to(self.device).contiguous()
+        if hist is None:
+            hist = torch.zeros((classes, classes), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gs_confusion_u8(self.map.data_ptr(), gt.data_ptr(), self.map.numel(), classes, hist.data_ptr(),
+                                                _sp(self.device)))
+        return hist

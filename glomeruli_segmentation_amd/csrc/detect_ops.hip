@@ -267,6 +267,61 @@ mask_nearest_kernel(const unsigned char *src, int h, int w, int oh, int ow, unsi
     out[idx] = src[(long long)sy * w + sx];
 }
 
+// ---------------------------------------------------------------------------------------------
+// WSI compositor
+__global__ void __launch_bounds__(256)
+wsi_paste_max_kernel(unsigned char *map, int map_h, int map_w, int ds, const unsigned char *crop, int h, int w, int x1,
+                     int y1, int X0, int Y0, int nx, int ny)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nx * ny)
+        return;
+    const int X = X0 + idx % nx, Y = Y0 + idx / nx;
+    const int cx = X * ds - x1, cy = Y * ds - y1;
+    if (X < 0 || Y < 0 || X >= map_w || Y >= map_h || cx < 0 || cy < 0 || cx >= w || cy >= h)
+        return;
+    const unsigned char v = crop[(long long)cy * w + cx];
+    unsigned char *dst = map + (long long)Y * map_w + X;
+    if (v > *dst)
+        *dst = v;
+}
+
+__global__ void __launch_bounds__(256)
+overlay_kernel(const unsigned char *region, const unsigned char *cls, long long npix, const unsigned char *pal, int ncol, float wa,
+               float wb, unsigned char *out)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= npix)
+        return;
+    const int c = cls[idx];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        // palette rows are RGB, the image is BGR (classMap_numpy_color[...] = [b, g, r])
+        const float col = c < ncol ? (float)pal[c * 3 + (2 - ch)] : 0.0f;
+        const float v = (float)region[idx * 3 + ch] * wa + col * wb;
+        out[idx * 3 + ch] = (unsigned char)fminf(fmaxf(rintf(v), 0.0f), 255.0f);   // saturate_cast<uchar>(cvRound)
+    }
+}
+
+__global__ void __launch_bounds__(256)
+confusion_kernel(const unsigned char *pred, const unsigned char *gt, long long n, int classes, unsigned long long *hist)
+{
+    extern __shared__ unsigned int lh[];
+    const int cells = classes * classes;
+    for (int i = threadIdx.x; i < cells; i += 256)
+        lh[i] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int g = gt[i], p = pred[i];
+        if (g < classes && p < classes)
+            atomicAdd(&lh[classes * g + p], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cells; i += 256)
+        if (lh[i])
+            atomicAdd(&hist[i], (unsigned long long)lh[i]);
+}
+
 }  // namespace gs
 
 using namespace gs;
@@ -293,6 +348,51 @@ gs_status gs_mask_resize_nearest(const uint8_t *mask, int h, int w, int out_h, i
     GS_REQUIRE(h > 0 && w > 0 && out_h > 0 && out_w > 0, "gs_mask_resize_nearest: bad size");
     hipLaunchKernelGGL(mask_nearest_kernel, dim3((out_h * out_w + 255) / 256), dim3(256), 0,
                        static_cast<hipStream_t>(hip_stream), mask, h, w, out_h, out_w, out);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+gs_status gs_wsi_paste_max(uint8_t *slide_map, int map_h, int map_w, int ds, const uint8_t *crop_mask, int h, int w, int x1,
+                           int y1, void *hip_stream)
+{
+    GS_REQUIRE(slide_map && crop_mask, "gs_wsi_paste_max: null pointer");
+    GS_REQUIRE(map_h > 0 && map_w > 0 && ds > 0 && h > 0 && w > 0, "gs_wsi_paste_max: bad size");
+    // footprint of the crop on the map grid: X with x1 <= ds*X < x1 + w
+    auto ceil_div = [](long long a, long long b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); };
+    const int X0 = (int)ceil_div(x1, ds), Y0 = (int)ceil_div(y1, ds);
+    const int X1 = (int)ceil_div((long long)x1 + w, ds), Y1 = (int)ceil_div((long long)y1 + h, ds);
+    const int nx = X1 - X0, ny = Y1 - Y0;
+    if (nx <= 0 || ny <= 0)
+        return GS_OK;
+    hipLaunchKernelGGL(wsi_paste_max_kernel, dim3((nx * ny + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                       slide_map, map_h, map_w, ds, crop_mask, h, w, x1, y1, X0, Y0, nx, ny);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+gs_status gs_overlay_classmap(const uint8_t *region_bgr, const uint8_t *class_map, int h, int w, const uint8_t *palette_rgb,
+                              int n_colours, float wa, float wb, uint8_t *out_bgr, void *hip_stream)
+{
+    GS_REQUIRE(region_bgr && class_map && palette_rgb && out_bgr, "gs_overlay_classmap: null pointer");
+    GS_REQUIRE(h > 0 && w > 0 && n_colours > 0, "gs_overlay_classmap: bad size");
+    const long long npix = (long long)h * w;
+    hipLaunchKernelGGL(overlay_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                       region_bgr, class_map, npix, palette_rgb, n_colours, wa, wb, out_bgr);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+gs_status gs_confusion_u8(const uint8_t *pred, const uint8_t *gt, long long n, int classes, unsigned long long *hist,
+                          void *hip_stream)
+{
+    GS_REQUIRE(pred && gt && hist, "gs_confusion_u8: null pointer");
+    GS_REQUIRE(n >= 0 && classes > 0 && classes <= 64, "gs_confusion_u8: bad size");
+    if (n == 0)
+        return GS_OK;
+    long long blocks = (n + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)blocks), dim3(256), (size_t)classes * classes * sizeof(unsigned),
+                       static_cast<hipStream_t>(hip_stream), pred, gt, n, classes, hist);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

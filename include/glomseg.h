@@ -97,6 +97,23 @@ gs_status gs_crop_preprocess(const uint8_t *crop_bgr, int h, int w, const float 
 gs_status gs_mask_resize_nearest(const uint8_t *mask, int h, int w, int out_h, int out_w, uint8_t *out,
                                  void *hip_stream);
 
+/* WSI compositor (the consumer of the gathered masks; eval_wsi_segmentation.py:243-316,215-241,359-394).
+ * The slide-level class map lives at 1/ds of level 0 (ds = 8 in the reference): pixel (X,Y) holds the
+ * class at level-0 pixel (ds*X, ds*Y), i.e. what INTER_NEAREST of a full 2400-px window yields (:229).
+ * gs_wsi_paste_max: max-composite one crop's class map (uint8 [h,w], level-0 resolution, top-left at
+ * level-0 (x1,y1)) into the slide map (uint8 [map_h,map_w]) -- np.max of window and crop (:311-312).
+ * Calls on one stream are ordered, so overlapping crops need no atomics.
+ * gs_overlay_classmap: palette colouring + cv2.addWeighted(region, wa, colour, wb) on a BGR uint8 image
+ * (:236-240; palette rows are RGB as in the reference table, 25 entries).
+ * gs_confusion_u8: iouEval.fast_hist (IOUEval.py:19-21): hist[classes*gt + pred] += 1 for gt < classes. */
+gs_status gs_wsi_paste_max(uint8_t *slide_map, int map_h, int map_w, int ds, const uint8_t *crop_mask, int h, int w,
+                           int x1, int y1, void *hip_stream);
+gs_status gs_overlay_classmap(const uint8_t *region_bgr, const uint8_t *class_map, int h, int w,
+                              const uint8_t *palette_rgb /*[n_colours*3] device*/, int n_colours, float wa, float wb,
+                              uint8_t *out_bgr, void *hip_stream);
+gs_status gs_confusion_u8(const uint8_t *pred, const uint8_t *gt, long long n, int classes,
+                          unsigned long long *hist /*[classes*classes] device, accumulated into*/, void *hip_stream);
+
 /* 5-fold style ensemble (BASELINE cfg 5; definition in DESIGN.md): probability = mean over
  * models of softmax(logits_k), each model with its own mean/std; writes argmax mask. */
 gs_status gs_espnet_ensemble_forward(gs_espnet *const *models, int n_models, const void *in_u8, int n,

@@ -338,3 +338,38 @@ def test_crop_stage_kernels(torch_mod):
         m = np.random.default_rng(h).integers(0, 5, (oh, ow)).astype(np.uint8)
         back = mask_resize_nearest(torch.from_numpy(m).cuda(), h, w).cpu().numpy()
         assert np.array_equal(back, imageops.resize_nearest(m, w, h)), (h, w)
+
+
+def test_wsi_compositor(torch_mod):
+    """GPU compositor vs a numpy restatement of eval_wsi_segmentation.py:243-316,215-241 (windows of
+    2400 px composited with np.max at full resolution, INTER_NEAREST to 1/8, palette + addWeighted)"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd import imageops
+    from glomeruli_segmentation_amd.composite import SlideCompositor
+    rng = np.random.default_rng(5)
+    W, H, win = 7200, 4800, 2400                     # multiples of the window: no edge-window quirks
+    boxes = []
+    for _ in range(25):
+        w, h = int(rng.integers(300, 1400)), int(rng.integers(300, 1400))
+        x1, y1 = int(rng.integers(0, W - w)), int(rng.integers(0, H - h))
+        boxes.append((x1, y1, x1 + w, y1 + h, rng.integers(0, 5, (h, w)).astype(np.uint8)))
+    comp = SlideCompositor(W, H, "cuda:0")
+    for x1, y1, x2, y2, m in boxes:
+        comp.paste(m, x1, y1)
+    # reference semantics in numpy
+    full = np.zeros((H, W), dtype=np.int64)
+    for x1, y1, x2, y2, m in boxes:
+        full[y1:y2, x1:x2] = np.maximum(full[y1:y2, x1:x2], m)
+    small = np.zeros((H // 8, W // 8), dtype=np.uint8)
+    for xi in range(W // win):
+        for yi in range(H // win):
+            wnd = full[yi * win:(yi + 1) * win, xi * win:(xi + 1) * win].astype(np.uint8)
+            small[yi * 300:(yi + 1) * 300, xi * 300:(xi + 1) * 300] = imageops.resize_nearest(wnd, 300, 300)
+    assert np.array_equal(comp.map.cpu().numpy(), small)
+    slide = rng.integers(0, 256, (H // 8, W // 8, 3)).astype(np.uint8)
+    blended = comp.overlay(slide).cpu().numpy()
+    assert np.array_equal(blended, imageops.add_weighted(slide, 0.4, imageops.colourise(small), 0.6))
+    gt = rng.integers(0, 5, small.shape).astype(np.uint8)
+    hist = comp.confusion(gt).cpu().numpy()
+    k = 5 * gt.astype(int).ravel() + small.astype(int).ravel()
+    assert np.array_equal(hist, np.bincount(k, minlength=25).reshape(5, 5))
