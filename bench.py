@@ -199,6 +199,18 @@ def main():
             "kernels_avg_ms": kernels,
             "parity": parity_vs_golden(mask[:4].cpu().numpy()),
         }
+        if n == 1:
+            # PCIe-inclusive rate (never `value`): pinned host uint8 tiles -> pinned host masks through the
+            # double-buffered H2D / compute / D2H pipeline of gs_espnet_segment_host
+            reps = 16
+            host_tiles = torch.from_numpy(np.concatenate([tiles_np] * reps)).pin_memory()
+            eng.segment_host(host_tiles[:2 * BATCH], mean, std, batch=BATCH)          # warm-up
+            t0 = time.perf_counter()
+            hm, hh = eng.segment_host(host_tiles, mean, std, batch=BATCH)
+            el = time.perf_counter() - t0
+            out["host_pipeline"] = {"value": round(reps * BATCH / el, 1), "unit": "patches/s", "tiles": reps * BATCH,
+                                    "note": "pinned host in -> pinned host out, PCIe inclusive; masks equal the resident path: %s"
+                                            % bool((hm[:BATCH] == mask.cpu().numpy()).all())}
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, tiles_np, mean, std)
         print(json.dumps(out))

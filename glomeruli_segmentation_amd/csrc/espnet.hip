@@ -75,6 +75,18 @@ struct Model {
     std::map<std::string, std::pair<Act, int>> stages;   // name -> (activation, channels) of the last forward
     int last_n = 0;
 
+    // host pipeline (gs_espnet_segment_host): two slots of pinned + device staging, kept across calls
+    struct Slot {
+        uint8_t *hin = nullptr, *hout = nullptr, *din = nullptr, *dout = nullptr;
+        unsigned long long *hh = nullptr, *dh = nullptr;
+        hipStream_t copy = nullptr;
+        hipEvent_t up = nullptr, done = nullptr, down = nullptr;
+        int first = -1, count = 0;
+    } sl[2];
+    hipStream_t pipe_compute = nullptr;
+    size_t pipe_in_bytes = 0, pipe_out_bytes = 0;
+    int pipe_batch = 0;
+
     // profiling
     bool profile = false;
     struct Ev { hipEvent_t a, b; int k; };
@@ -552,6 +564,25 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     return L.st;
 }
 
+static void free_pipeline(Model &m)
+{
+    for (auto &s : m.sl) {
+        if (s.hin) hipHostFree(s.hin);
+        if (s.hout) hipHostFree(s.hout);
+        if (s.hh) hipHostFree(s.hh);
+        if (s.din) hipFree(s.din);
+        if (s.dout) hipFree(s.dout);
+        if (s.dh) hipFree(s.dh);
+        if (s.copy) hipStreamDestroy(s.copy);
+        if (s.up) hipEventDestroy(s.up);
+        if (s.done) hipEventDestroy(s.done);
+        if (s.down) hipEventDestroy(s.down);
+        s = Model::Slot();
+    }
+    m.pipe_in_bytes = m.pipe_out_bytes = 0;
+    m.pipe_batch = 0;
+}
+
 }  // namespace gs
 
 using namespace gs;
@@ -692,6 +723,8 @@ void gs_espnet_destroy(gs_espnet *h)
         hipEventDestroy(ev.a);
         hipEventDestroy(ev.b);
     }
+    free_pipeline(h->m);
+    if (h->m.pipe_compute) hipStreamDestroy(h->m.pipe_compute);
     if (h->m.ws) hipFree(h->m.ws);
     if (h->m.prob) hipFree(h->m.prob);
     if (h->m.dblob) hipFree(h->m.dblob);
@@ -851,15 +884,21 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
     st = layout_workspace(&h->m, batch, height, width);
     if (st != GS_OK) return st;
     const size_t in_b = (size_t)height * width * 3, out_b = (size_t)height * width;
+    // caller buffers that are already page-locked (hipHostMalloc / hipHostRegister) are DMA'd in place;
+    // pageable ones are staged through the pinned slot buffers with a host memcpy
+    auto is_pinned = [](const void *p) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return at.type == hipMemoryTypeHost;
+    };
+    const bool in_pinned = is_pinned(tiles), out_pinned = is_pinned(masks) && (!hist || is_pinned(hist));
     // two slots: while slot s computes, slot s^1 uploads the next batch and downloads the previous masks
-    struct Slot {
-        uint8_t *hin = nullptr, *hout = nullptr, *din = nullptr, *dout = nullptr;
-        unsigned long long *hh = nullptr, *dh = nullptr;
-        hipStream_t copy = nullptr;
-        hipEvent_t up = nullptr, done = nullptr, down = nullptr;
-        int first = -1, count = 0;
-    } sl[2];
-    hipStream_t compute = nullptr;
+    Model &m = h->m;
+    using Slot = Model::Slot;
+    Slot *sl = m.sl;
     gs_status rc = GS_OK;
     auto fail = [&](hipError_t e, const char *what) {
         if (e != hipSuccess && rc == GS_OK) {
@@ -868,25 +907,37 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         }
         return e != hipSuccess;
     };
-    fail(hipStreamCreateWithFlags(&compute, hipStreamNonBlocking), "hipStreamCreate");
-    for (auto &s : sl) {
-        fail(hipHostMalloc(reinterpret_cast<void **>(&s.hin), in_b * batch, hipHostMallocDefault), "hipHostMalloc");
-        fail(hipHostMalloc(reinterpret_cast<void **>(&s.hout), out_b * batch, hipHostMallocDefault), "hipHostMalloc");
-        fail(hipHostMalloc(reinterpret_cast<void **>(&s.hh), sizeof(unsigned long long) * 5 * batch, hipHostMallocDefault), "hipHostMalloc");
-        fail(hipMalloc(reinterpret_cast<void **>(&s.din), in_b * batch), "hipMalloc");
-        fail(hipMalloc(reinterpret_cast<void **>(&s.dout), out_b * batch), "hipMalloc");
-        fail(hipMalloc(reinterpret_cast<void **>(&s.dh), sizeof(unsigned long long) * 5 * batch), "hipMalloc");
-        fail(hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking), "hipStreamCreate");
-        fail(hipEventCreateWithFlags(&s.up, hipEventDisableTiming), "hipEventCreate");
-        fail(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
-        fail(hipEventCreateWithFlags(&s.down, hipEventDisableTiming), "hipEventCreate");
+    if (!m.pipe_compute)
+        fail(hipStreamCreateWithFlags(&m.pipe_compute, hipStreamNonBlocking), "hipStreamCreate");
+    hipStream_t compute = m.pipe_compute;
+    if (m.pipe_in_bytes < in_b * batch || m.pipe_out_bytes < out_b * batch || m.pipe_batch < batch) {
+        free_pipeline(m);
+        for (int i = 0; i < 2; ++i) {
+            Slot &s = sl[i];
+            fail(hipHostMalloc(reinterpret_cast<void **>(&s.hin), in_b * batch, hipHostMallocDefault), "hipHostMalloc");
+            fail(hipHostMalloc(reinterpret_cast<void **>(&s.hout), out_b * batch, hipHostMallocDefault), "hipHostMalloc");
+            fail(hipHostMalloc(reinterpret_cast<void **>(&s.hh), sizeof(unsigned long long) * 5 * batch, hipHostMallocDefault), "hipHostMalloc");
+            fail(hipMalloc(reinterpret_cast<void **>(&s.din), in_b * batch), "hipMalloc");
+            fail(hipMalloc(reinterpret_cast<void **>(&s.dout), out_b * batch), "hipMalloc");
+            fail(hipMalloc(reinterpret_cast<void **>(&s.dh), sizeof(unsigned long long) * 5 * batch), "hipMalloc");
+            fail(hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking), "hipStreamCreate");
+            fail(hipEventCreateWithFlags(&s.up, hipEventDisableTiming), "hipEventCreate");
+            fail(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
+            fail(hipEventCreateWithFlags(&s.down, hipEventDisableTiming), "hipEventCreate");
+        }
+        m.pipe_in_bytes = in_b * batch;
+        m.pipe_out_bytes = out_b * batch;
+        m.pipe_batch = batch;
     }
+    sl[0].first = sl[1].first = -1;
     auto drain = [&](Slot &s) {   // wait for the slot's masks and hand them to the caller
         if (s.first < 0 || rc != GS_OK)
             return;
         if (fail(hipEventSynchronize(s.down), "hipEventSynchronize")) return;
-        std::memcpy(masks + (size_t)s.first * out_b, s.hout, out_b * s.count);
-        if (hist) std::memcpy(hist + (size_t)s.first * 5, s.hh, sizeof(unsigned long long) * 5 * s.count);
+        if (!out_pinned) {
+            std::memcpy(masks + (size_t)s.first * out_b, s.hout, out_b * s.count);
+            if (hist) std::memcpy(hist + (size_t)s.first * 5, s.hh, sizeof(unsigned long long) * 5 * s.count);
+        }
         s.first = -1;
     };
     int slot = 0;
@@ -895,8 +946,12 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         drain(s);   // the slot's previous batch must have left its pinned buffers
         if (rc != GS_OK) break;
         const int cnt = n_tiles - first < batch ? n_tiles - first : batch;
-        std::memcpy(s.hin, tiles + (size_t)first * in_b, in_b * cnt);
-        if (fail(hipMemcpyAsync(s.din, s.hin, in_b * cnt, hipMemcpyHostToDevice, s.copy), "H2D copy")) break;
+        const uint8_t *src = tiles + (size_t)first * in_b;
+        if (!in_pinned) {
+            std::memcpy(s.hin, src, in_b * cnt);
+            src = s.hin;
+        }
+        if (fail(hipMemcpyAsync(s.din, src, in_b * cnt, hipMemcpyHostToDevice, s.copy), "H2D copy")) break;
         fail(hipEventRecord(s.up, s.copy), "hipEventRecord");
         fail(hipStreamWaitEvent(compute, s.up, 0), "hipStreamWaitEvent");
         gs_status st2 = gs_espnet_forward(h, s.din, GS_IN_U8_BGR_NHWC, cnt, height, width, mean, std, nullptr, s.dout,
@@ -904,28 +959,18 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         if (st2 != GS_OK) { rc = st2; break; }
         fail(hipEventRecord(s.done, compute), "hipEventRecord");
         fail(hipStreamWaitEvent(s.copy, s.done, 0), "hipStreamWaitEvent");
-        fail(hipMemcpyAsync(s.hout, s.dout, out_b * cnt, hipMemcpyDeviceToHost, s.copy), "D2H copy");
-        fail(hipMemcpyAsync(s.hh, s.dh, sizeof(unsigned long long) * 5 * cnt, hipMemcpyDeviceToHost, s.copy), "D2H copy");
+        fail(hipMemcpyAsync(out_pinned ? masks + (size_t)first * out_b : s.hout, s.dout, out_b * cnt, hipMemcpyDeviceToHost, s.copy), "D2H copy");
+        if (hist || !out_pinned)
+            fail(hipMemcpyAsync(out_pinned ? reinterpret_cast<void *>(hist + (size_t)first * 5) : reinterpret_cast<void *>(s.hh), s.dh,
+                                sizeof(unsigned long long) * 5 * cnt, hipMemcpyDeviceToHost, s.copy), "D2H copy");
         fail(hipEventRecord(s.down, s.copy), "hipEventRecord");
         s.first = first;
         s.count = cnt;
     }
     drain(sl[slot]);
     drain(sl[slot ^ 1]);
-    hipDeviceSynchronize();
-    for (auto &s : sl) {
-        if (s.hin) hipHostFree(s.hin);
-        if (s.hout) hipHostFree(s.hout);
-        if (s.hh) hipHostFree(s.hh);
-        if (s.din) hipFree(s.din);
-        if (s.dout) hipFree(s.dout);
-        if (s.dh) hipFree(s.dh);
-        if (s.copy) hipStreamDestroy(s.copy);
-        if (s.up) hipEventDestroy(s.up);
-        if (s.done) hipEventDestroy(s.done);
-        if (s.down) hipEventDestroy(s.down);
-    }
-    if (compute) hipStreamDestroy(compute);
+    if (rc != GS_OK)
+        hipDeviceSynchronize();
     return rc;
 }
 

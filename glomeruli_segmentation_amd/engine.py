@@ -125,6 +125,19 @@ class EspnetEngine:
     def segment_host(self, tiles, mean, std, batch=32, want_hist=True):
         """numpy uint8 [T,H,W,3] in host memory -> (masks [T,H,W], counts [T,classes]) through the
         pinned double-buffered H2D / compute / D2H pipeline of the library."""
+        if isinstance(tiles, torch.Tensor):      # e.g. a pinned CPU tensor: DMA'd in place, no staging copy
+            if tiles.is_cuda or tiles.dtype != torch.uint8 or not tiles.is_contiguous():
+                raise ValueError("expected a contiguous uint8 CPU tensor")
+            t, h, w, _ = tiles.shape
+            in_ptr = ctypes.c_void_p(tiles.data_ptr())
+            pin = tiles.is_pinned()
+            masks_t = torch.empty((t, h, w), dtype=torch.uint8, pin_memory=pin)
+            hist_t = torch.zeros((t, self.classes), dtype=torch.int64, pin_memory=pin) if want_hist else None
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.gs_espnet_segment_host(
+                    self.handle, in_ptr, t, h, w, _lib.fptr3(mean), _lib.fptr3(std), batch, ctypes.c_void_p(masks_t.data_ptr()),
+                    ctypes.c_void_p(hist_t.data_ptr()) if want_hist else None))
+            return masks_t.numpy(), (hist_t.numpy() if want_hist else None)
         tiles = np.ascontiguousarray(tiles, dtype=np.uint8)
         t, h, w, _ = tiles.shape
         masks = np.empty((t, h, w), dtype=np.uint8)

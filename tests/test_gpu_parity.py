@@ -373,3 +373,14 @@ def test_wsi_compositor(torch_mod):
     hist = comp.confusion(gt).cpu().numpy()
     k = 5 * gt.astype(int).ravel() + small.astype(int).ravel()
     assert np.array_equal(hist, np.bincount(k, minlength=25).reshape(5, 5))
+
+
+def test_host_pipeline_pinned_in_place(torch_mod, engine1):
+    """page-locked caller buffers are DMA'd in place (no staging memcpy) and give the same masks"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    mean, std = FOLD_MEAN_STD[1]
+    tiles = np.stack([synth_tile(s, 128, 256, blobs=4) for s in range(5)])
+    m1, h1 = engine1.segment_host(tiles, mean, std, batch=2)
+    m2, h2 = engine1.segment_host(torch.from_numpy(tiles).pin_memory(), mean, std, batch=2)
+    assert np.array_equal(m1, m2) and np.array_equal(h1, h2)
