@@ -50,6 +50,9 @@ PROTOTYPES = {
     "gs_espnet_profile_read": (_I, [_P, ctypes.POINTER(KernelTime), _I, ctypes.POINTER(_I)]),
     "gs_crop_preprocess": (_I, [_P, _I, _I, _FP, _FP, _I, _I, _P, _P]),
     "gs_mask_resize_nearest": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "gs_find_contours": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "gs_arc_length_closed": (ctypes.c_double, [_P, _I]),
+    "gs_approx_poly_closed": (_I, [_P, _I, ctypes.c_double, _P]),
     "gs_wsi_paste_max": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _P]),
     "gs_overlay_classmap": (_I, [_P, _P, _I, _I, _P, _I, ctypes.c_float, ctypes.c_float, _P, _P]),
     "gs_confusion_u8": (_I, [_P, _P, ctypes.c_longlong, _I, _P, _P]),

@@ -12,7 +12,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libglomseg.so")
-SOURCES = ["espnet.hip", "detect_ops.hip"]
+SOURCES = ["espnet.hip", "detect_ops.hip", "contours.cpp"]
 HEADERS = ["gs_internal.h", "conv_mfma.h", "espnet_kernels.h", os.path.join("..", "..", "include", "glomseg.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
          "-Wno-unused-value"] + os.environ.get("GS_EXTRA_HIPCC_FLAGS", "").split()
@@ -33,9 +33,9 @@ def build_lib(force=False, verbose=False):
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(CSRC, s.replace(".hip", ".o"))
+        o = os.path.join(CSRC, s.replace(".hip", ".o").replace(".cpp", ".o"))
         objs.append(o)
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

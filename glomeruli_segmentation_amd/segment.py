@@ -126,13 +126,13 @@ def evaluate(args, engine, rgb_list, label_list):
             out_map = imageops.relabel_city(cmap) if args.cityFormat else cmap                     # :158-159
             # The reference stores the ORIGINAL crop in the JSON's imageData (:179) although the WSI
             # compositor reads it as a class map; this build writes the class map
-            # itself beside the JSON and records its name, and leaves polygon extraction (cv2
-            # findContours/approxPolyDP, boundary_extractor.py) to the "next" row of SURVEY 8f.
+            # itself beside the JSON and records its name; polygons come from contours.py (the build's
+            # restatement of boundary_extractor.py, cv2 being absent).
             from PIL import Image
             Image.fromarray(out_map).save(os.path.join(odir, stem + "_classmap.png"))
+            from .contours import labelme_dict
             with open(os.path.join(odir, name.replace(args.img_extn, 'json')), 'w') as f:
-                json.dump({"shapes": [], "lineColor": [0, 0, 0, 255], "imagePath": name, "flags": {},
-                           "fillColor": [0, 0, 0, 255], "classMapPath": stem + "_classmap.png"}, f, indent=4)
+                json.dump(labelme_dict(out_map, name, stem + "_classmap.png"), f, indent=4)        # :161-182
             if label_name is not None:
                 assert os.path.basename(img_name) == os.path.basename(label_name)
                 lab = np.asarray(Image.open(label_name))

@@ -114,6 +114,15 @@ gs_status gs_overlay_classmap(const uint8_t *region_bgr, const uint8_t *class_ma
 gs_status gs_confusion_u8(const uint8_t *pred, const uint8_t *gt, long long n, int classes,
                           unsigned long long *hist /*[classes*classes] device, accumulated into*/, void *hip_stream);
 
+/* Host-side polygon extraction for the per-crop labelme JSON (boundary_extractor.py:33-47): borders of a binary
+ * uint8 image (Suzuki-Abe border following, every outer and hole border = RETR_LIST; simple != 0 keeps only the
+ * points where the direction changes = CHAIN_APPROX_SIMPLE), perimeter and Ramer-Douglas-Peucker simplification of
+ * a closed curve.  Pure host code (no device work).  gs_find_contours with points == NULL only reports the sizes. */
+gs_status gs_find_contours(const uint8_t *img, int h, int w, int simple, int *points /*xy pairs*/, int cap_points,
+                           int *offsets /*n_contours+1*/, int cap_contours, int *n_contours, int *n_points);
+double gs_arc_length_closed(const int *xy, int n);
+int gs_approx_poly_closed(const int *xy, int n, double epsilon, int *out_xy);
+
 /* 5-fold style ensemble (BASELINE cfg 5; definition in DESIGN.md): probability = mean over
  * models of softmax(logits_k), each model with its own mean/std; writes argmax mask. */
 gs_status gs_espnet_ensemble_forward(gs_espnet *const *models, int n_models, const void *in_u8, int n,

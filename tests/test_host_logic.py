@@ -270,3 +270,48 @@ def test_merge_csv_contracts(tmp_path):
     lists, order = merge.read_merged_csv(str(out))
     assert order == ["PAS001", "PAS002"] and lists["PAS001"][0] == [8800, 17520, 10480, 19280, 0.9]
     assert merge.crop_name(lists["PAS001"][0]) == "xmin1100_ymin2190_xmax1310_ymax2410"
+
+
+def test_contours_and_polygons():
+    """host contour tracer + polygon simplifier: geometric invariants (cv2 parity is unpinned)"""
+    from glomeruli_segmentation_amd import contours
+    img = np.zeros((40, 60), np.uint8)
+    img[5:25, 10:40] = 1            # a rectangle ...
+    img[10:20, 20:30] = 0           # ... with a hole
+    img[30:33, 50:53] = 1           # and a small blob
+    cs = contours.find_contours(img)
+    assert len(cs) == 3                                               # outer, hole, blob (RETR_LIST keeps holes)
+    outer = [c for c in cs if c[:, 0, 0].min() == 10 and c[:, 0, 0].max() == 39][0]
+    assert sorted(map(tuple, outer[:, 0, :].tolist())) == [(10, 5), (10, 24), (39, 5), (39, 24)]   # CHAIN_APPROX_SIMPLE: corners only
+    hole = [c for c in cs if c[:, 0, 0].min() == 19][0]               # a hole border runs on the foreground ring around it
+    assert hole[:, 0, 0].max() == 30 and hole[:, 0, 1].min() == 9 and hole[:, 0, 1].max() == 20
+    full = contours.find_contours(img, simple=False)
+    assert max(len(c) for c in full) == 2 * (30 + 20) - 4            # every border pixel of the rectangle once
+    assert abs(contours.arc_length(outer) - 2 * (29 + 19)) < 1e-9
+    # a disc: every border point lies on the disc's boundary, the polygon stays within epsilon of it
+    yy, xx = np.mgrid[0:200, 0:200]
+    disc = ((yy - 100) ** 2 + (xx - 100) ** 2 <= 70 ** 2).astype(np.uint8)
+    c = contours.find_contours(disc, simple=False)[0][:, 0, :]
+    r = np.hypot(c[:, 0] - 100, c[:, 1] - 100)
+    assert r.min() > 68.5 and r.max() <= 70.0 and len(c) > 350
+    assert (np.abs(np.diff(np.vstack([c, c[:1]]), axis=0)).max(axis=1) == 1).all()      # 8-connected closed chain
+    eps = 0.003 * contours.arc_length(c)
+    poly = contours.approx_poly(c, eps)[:, 0, :]
+    assert 8 <= len(poly) < len(c) // 4
+    seg_a, seg_b = poly, np.roll(poly, -1, axis=0)
+    for p in c[::7]:                                                  # each original point is within eps of the polygon
+        d = []
+        for a, b in zip(seg_a, seg_b):
+            ab, ap = (b - a).astype(float), (p - a).astype(float)
+            t = np.clip(ap @ ab / max(ab @ ab, 1e-12), 0, 1)
+            d.append(np.hypot(*(ap - t * ab)))
+        assert min(d) <= eps + 1e-9
+    gy, gx = np.mgrid[0:300, 0:300]
+    cm = np.zeros((300, 300), np.uint8)
+    cm[(gy - 150) ** 2 + (gx - 150) ** 2 <= 120 ** 2] = 1
+    cm[(gy - 160) ** 2 + (gx - 170) ** 2 <= 35 ** 2] = 3          # round blob: many direction changes
+    cm[20:24, 20:24] = 2                                            # 4-corner speck: below o_min_points, dropped as noise
+    d = contours.labelme_dict(cm, "x.PNG")
+    labels = [s["label"] for s in d["shapes"]]
+    assert labels.count("glomerulus") == 1 and labels.count("sclerosis") == 1 and "crescent" not in labels
+    assert d["imagePath"] == "x.PNG" and all(len(s["points"]) >= 3 for s in d["shapes"])
