@@ -156,6 +156,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     const int tasks_per_img = a.H * a.strips;
     bool staged = false;
 
+    // operand ring (see below); it lives across tasks: the last chunk of a task refills it with the first
+    // chunk of the wave's NEXT task, so only a wave's very first loads are exposed
+    float aq[D], bq[D][P];
+
     for (int task = t0; task < t1 || !staged; task += tstride) {
         const bool idle = task >= t1;   // a wave without work still has to help stage the weights
         const int tk = idle ? (a.total_tasks - 1) : task;
@@ -167,6 +171,14 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.in + (long long)n * a.in_sn), 0, a.in_img_bytes, 0x00020000);
         const int sbase = (a.in_off + y * STRIDE * a.in_pitch + x0 * STRIDE) * 4;
+        // the wave's next task (itself when this is the last one: a harmless redundant prefetch)
+        const int tn = task + tstride < t1 ? task + tstride : tk;
+        const int n_n = tn / tasks_per_img;
+        const int rem_n = tn - n_n * tasks_per_img;
+        const int y_n = rem_n / a.strips;
+        const __amdgpu_buffer_rsrc_t rsrc_n = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(a.in + (long long)n_n * a.in_sn), 0, a.in_img_bytes, 0x00020000);
+        const int sbase_n = (a.in_off + y_n * STRIDE * a.in_pitch + (rem_n - y_n * a.strips) * (P * MT) * STRIDE) * 4;
         const __amdgpu_buffer_rsrc_t rout =
             __builtin_amdgcn_make_buffer_rsrc(a.out + (long long)n * a.out_sn, 0, a.out_img_bytes, 0x00020000);
         const int sout = (a.out_off + y * a.out_pitch + x0) * 4;
@@ -218,15 +230,14 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         // issued: SQ_WAIT_ANY 57 % of wave cycles, MFMA pipe 42 % busy.)  The three horizontal taps
         // of a row are consecutive steps, so two of three B loads hit lines the wave has just pulled
         // into L1.
-        float aq[D], bq[D][P];
         // operands of chunk c (dilation c / CPD, row groups (c % CPD)*G ..) into ring slots 0..D-1
-        auto fetch_b = [&](int c, int g, int tx) {
+        auto fetch_b = [&](const __amdgpu_buffer_rsrc_t &rs, int sb, int c, int g, int tx) {
             const int di = c / CPD;
             const int rg = (c - di * CPD) * G + g;
             const int ty = rg / NSTEP;
             const int sidx = rg - ty * NSTEP;
             const int toff = TAPS == 9 ? ((ty - 1) * a.in_pitch + (tx - 1)) << di : 0;
-            const int soff = sbase + (toff + sidx * KL * a.in_sc) * 4;
+            const int soff = sb + (toff + sidx * KL * a.in_sc) * 4;
             if (FLAGS & F_X_NOLOAD) {
 #pragma unroll
                 for (int p = 0; p < P; ++p)
@@ -236,7 +247,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 #pragma unroll
             for (int p = 0; p < P; ++p)
                 bq[g * TXN + tx][p] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + p * MT * STRIDE * 4, soff, 0));
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + p * MT * STRIDE * 4, soff, 0));
         };
         auto fetch_a = [&](int c, int g, int tx) {
             const int di = c / CPD;
@@ -253,11 +264,13 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 
         // prologue: the first chunk's activations are requested before the weights are staged, so
         // their latency overlaps the LDS fill
+        if (task == t0) {
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+            for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int tx = 0; tx < TXN; ++tx)
-                fetch_b(0, g, tx);
+                for (int tx = 0; tx < TXN; ++tx)
+                    fetch_b(rsrc, sbase, 0, g, tx);
+        }
         if (!staged) {
             // weights -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR
             // round trip), every piece in flight at once; a register-staged copy loop took 9 us of a
@@ -283,11 +296,13 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
             for (int z = 0; z < a.stagger * ph; ++z)
                 __builtin_amdgcn_s_sleep(16);
         }
+        if (task == t0) {
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+            for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int tx = 0; tx < TXN; ++tx)
-                fetch_a(0, g, tx);
+                for (int tx = 0; tx < TXN; ++tx)
+                    fetch_a(0, g, tx);
+        }
 
         prefetch_res(0);
 
@@ -306,7 +321,11 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                 for (int p = 0; p < P; ++p)
                     acc[p] = (typename M::acc_t)(0.0f);
             }
-            const int nx = c + 1 < NCHUNK ? c + 1 : c;   // the last chunk refetches itself (unused)
+            // the ring is refilled with the next chunk of this task, or with chunk 0 of the next task
+            const bool last = c + 1 == NCHUNK;
+            const int nx = last ? 0 : c + 1;
+            const __amdgpu_buffer_rsrc_t rs = last ? rsrc_n : rsrc;
+            const int sb = last ? sbase_n : sbase;
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -315,7 +334,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 #pragma unroll
                     for (int p = 0; p < P; ++p)
                         acc[p] = M::run(aq[u], bq[u][p], acc[p]);
-                    fetch_b(nx, g, tx);
+                    fetch_b(rs, sb, nx, g, tx);
                     fetch_a(nx, g, tx);
                     // pin the ring order: left alone, hipcc sinks the refill loads to the end of the
                     // chunk, which shrinks the prefetch distance from D steps to a few

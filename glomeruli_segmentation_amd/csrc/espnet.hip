@@ -38,7 +38,7 @@ void set_error(const char *fmt, ...)
 #define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 3
 #define CFG_L3_BR_W16    32, 16,  26,  9,   1,     5,   28,   25,   2, 3
 #define CFG_L3_BR_P2     32, 8,   26,  9,   1,     5,   28,   25,   2, 13
-#define CFG_DEC_CONV     16, 8,   28,  9,   1,     1,   5,    5,    8, 3
+#define CFG_DEC_CONV     16, 8,   24,  9,   1,     1,   5,    5,    8, 3
 
 enum KernelId {
     K_STEM, K_POOL, K_L2_C1S, K_L2_DOWN, K_L2_C1, K_L2_ESP, K_CAT_B2, K_L3_C1S, K_L3_DOWN, K_L3_C1, K_L3_ESP,
@@ -211,7 +211,9 @@ static Act make_act(int C, int Cp, int H, int W, int pad_t, int pad_b, int pad_l
     a.H = H;
     a.W = W;
     a.pitch = (int)round_up(pad_l + W + pad_r, 32);   // 128-byte rows: interior stores stay line-aligned
-    a.sc = (pad_t + H + pad_b) * a.pitch;
+    // + 96 floats: a plane stride that is a power of two (8192 floats at 1/8 scale) lands every channel of a
+    // pixel on the same HBM channel / L2 slice when a kernel walks the channels (dec1, the 1x1 reduces)
+    a.sc = (pad_t + H + pad_b) * a.pitch + 96;
     a.off = pad_t * a.pitch + pad_l;
     a.sn = (long long)Cp * a.sc;
     return a;
@@ -228,10 +230,12 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
     }
     const int cls = m->classes;
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8;
-    // output0_cat (planes 0..18) shares one buffer with comb_l2_l3 (planes 20..24, written by dec3): the
+    // output0_cat (planes 0..18) shares one buffer with comb_l2_l3 (planes 19..23, written by dec3): the
     // decoder's conv CBR(19+classes, classes, 3) then reads its torch.cat input (Model.py:375) as ONE
-    // 28-plane activation (planes 19 and 25..27 stay zero), with zero pad on all four sides
-    m->a0 = make_act(19, 28, H1, W1, 1, 1, 32, 1);
+    // 24-plane activation with zero pad on all four sides.  The level-2 strided reduce reads planes 0..19 of
+    // it (channel count padded to a multiple of 4) with zero weights on plane 19, whose content is
+    // therefore irrelevant as long as it is finite (zero after layout, comb_l2_l3 of the last forward after).
+    m->a0 = make_act(19, 19 + cls, H1, W1, 1, 1, 32, 1);
     m->inp1 = make_act(3, 3, H1, W1, 0, 0, 0, 0);
     m->inp2 = make_act(3, 3, H2, W2, 0, 0, 0, 0);
     m->r2 = make_act(12, 12, H2, W2, 16, 16, 32, 16);  // dilation up to 16
@@ -261,8 +265,8 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
         a->base = reinterpret_cast<float *>(static_cast<char *>(ws) + at);
         at += round_up(a->bytes(n) + slack, 256);
     }
-    m->ee = m->a0;   // comb_l2_l3 = planes 20.. of the output0_cat buffer
-    m->ee.base = m->a0.base + (long long)20 * m->a0.sc;
+    m->ee = m->a0;   // comb_l2_l3 = planes 19.. of the output0_cat buffer
+    m->ee.base = m->a0.base + (long long)19 * m->a0.sc;
     m->ee.C = cls;
     m->ws = ws;
     m->ws_bytes = total;
@@ -691,18 +695,18 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
         m.bnu2 = bb.push(tmp.data(), 3 * c);
         if (!(w = t.get("conv.conv.weight", {c, 19 + c, 3, 3}))) return GS_ERR_INVALID;
         {
-            // LDS image [tap][28 planes][c]: plane p < 19 is output0_cat channel p = cat channel c + p,
-            // plane 20 + j is comb_l2_l3 channel j = cat channel j (Model.py:375 cat order), rest zero
-            m.wconv = bb.reserve(conv_wfloats(28, 9, 1, c, c, true));
+            // LDS image [tap][24 planes][c]: plane p < 19 is output0_cat channel p = cat channel c + p,
+            // plane 19 + j is comb_l2_l3 channel j = cat channel j (Model.py:375 cat order)
+            const int npl = 19 + c;
+            m.wconv = bb.reserve(conv_wfloats(npl, 9, 1, c, c, true));
             float *dst = bb.data.data() + m.wconv;
             for (int tap = 0; tap < 9; ++tap)
-                for (int pl = 0; pl < 28; ++pl) {
-                    const int wch = pl < 19 ? c + pl : (pl >= 20 && pl < 20 + c ? pl - 20 : -1);
-                    if (wch < 0) continue;
+                for (int pl = 0; pl < npl; ++pl) {
+                    const int wch = pl < 19 ? c + pl : pl - 19;
                     for (int co = 0; co < c; ++co)
-                        dst[((size_t)tap * 28 + pl) * c + co] = w[((size_t)co * (19 + c) + wch) * 9 + tap];
+                        dst[((size_t)tap * npl + pl) * c + co] = w[((size_t)co * (19 + c) + wch) * 9 + tap];
                 }
-            if (!fold_bn(t, "conv.bn", "conv.act", c, dst + (size_t)9 * 28 * c)) return GS_ERR_INVALID;
+            if (!fold_bn(t, "conv.bn", "conv.act", c, dst + (size_t)9 * npl * c)) return GS_ERR_INVALID;
         }
         if (!(w = t.get("classifier.weight", {c, c, 2, 2}))) return GS_ERR_INVALID;
         m.wclassifier = bb.push(w, (size_t)c * c * 4);
