@@ -384,3 +384,100 @@ def test_host_pipeline_pinned_in_place(torch_mod, engine1):
     m1, h1 = engine1.segment_host(tiles, mean, std, batch=2)
     m2, h2 = engine1.segment_host(torch.from_numpy(tiles).pin_memory(), mean, std, batch=2)
     assert np.array_equal(m1, m2) and np.array_equal(h1, h2)
+
+
+def _random_state_dict(p, q, classes=5, seed=0):
+    """random-init weights of the ESPNet(classes, p, q) architecture (shapes per Model.py:242-339)"""
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = (rng.standard_normal((co, ci, k, k)) * (1.5 / np.sqrt(ci * k * k))).astype(np.float32)
+
+    def bn(name, c):
+        sd[name + ".weight"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+        sd[name + ".bias"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        sd[name + ".running_mean"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        sd[name + ".running_var"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+        sd[name + ".num_batches_tracked"] = np.array(1, dtype=np.int64)
+
+    def act(name, c):
+        sd[name + ".weight"] = rng.uniform(0.05, 0.4, c).astype(np.float32)
+
+    def block(pre, cin, cout, down):
+        n = cout // 5
+        n1 = cout - 4 * n
+        conv(pre + ".c1.conv", n, cin, 3 if down else 1)
+        conv(pre + ".d1.conv", n1, n, 3)
+        for d in (2, 4, 8, 16):
+            conv(pre + ".d%d.conv" % d, n, n, 3)
+        if down:
+            bn(pre + ".bn", cout)
+            act(pre + ".act", cout)
+        else:
+            bn(pre + ".bn.bn", cout)
+            act(pre + ".bn.act", cout)
+
+    e = "encoder."
+    conv(e + "level1.conv", 16, 3, 3); bn(e + "level1.bn", 16); act(e + "level1.act", 16)
+    bn(e + "b1.bn", 19); act(e + "b1.act", 19)
+    block(e + "level2_0", 19, 64, True)
+    for i in range(p):
+        block(e + "level2.%d" % i, 64, 64, False)
+    bn(e + "b2.bn", 131); act(e + "b2.act", 131)
+    block(e + "level3_0", 131, 128, True)
+    for i in range(q):
+        block(e + "level3.%d" % i, 128, 128, False)
+    bn(e + "b3.bn", 256); act(e + "b3.act", 256)
+    conv(e + "classifier.conv", classes, 256, 1)
+    conv("level3_C.conv", classes, 131, 1)
+    bn("br", classes)
+    conv("conv.conv", classes, 19 + classes, 3); bn("conv.bn", classes); act("conv.act", classes)
+    sd["up_l3.0.weight"] = (rng.standard_normal((classes, classes, 2, 2)) * 0.4).astype(np.float32)
+    bn("combine_l2_l3.0.bn", 2 * classes); act("combine_l2_l3.0.act", 2 * classes)
+    conv("combine_l2_l3.1.conv", classes, 2 * classes, 3); bn("combine_l2_l3.1.bn", classes); act("combine_l2_l3.1.act", classes)
+    sd["up_l2.0.weight"] = (rng.standard_normal((classes, classes, 2, 2)) * 0.4).astype(np.float32)
+    bn("up_l2.1.bn", classes); act("up_l2.1.act", classes)
+    sd["classifier.weight"] = (rng.standard_normal((classes, classes, 2, 2)) * 0.4).astype(np.float32)
+    return sd
+
+
+@pytest.mark.parametrize("p,q", [(2, 3), (1, 2), (0, 1), (3, 0)])
+def test_other_depths_random_weights(torch_mod, p, q):
+    """ESPNet(classes, p, q) for depths other than the shipped (2, 8) -- incl. p = 0 (unfused b2 path) and q = 0 --
+    with random-init weights, HIP path vs the CPU oracle"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.engine import EspnetEngine
+    from glomeruli_segmentation_amd.synth import noise_tile
+    from oracle import espnet_oracle as orc
+    sd = _random_state_dict(p, q, seed=10 * p + q)
+    eng = EspnetEngine(sd, classes=5, p=p, q=q)
+    tile = noise_tile(77, 48, 104)
+    mean, std = (120.0, 130.0, 110.0), (60.0, 55.0, 70.0)
+    lg_ref, mask_ref, hist_ref = orc.segment_tile(tile, sd, mean, std, p, q)
+    mask, hist, logits = eng.segment(torch.from_numpy(tile[None]).cuda(), mean, std, want_logits=True)
+    got = logits[0].cpu().numpy()
+    assert np.abs(got - lg_ref).max() <= 5e-4 * max(1.0, float(np.abs(lg_ref).max()))
+    assert (mask[0].cpu().numpy() != mask_ref).mean() <= 2e-3
+    eng.close()
+
+
+def test_full_batch_properties(torch_mod, engine1):
+    """BASELINE batch (32 x 1024x512): size-independent properties -- idempotence, permutation equivariance,
+    counts sum to the pixel count, logits argmax equals the fused mask"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    mean, std = FOLD_MEAN_STD[1]
+    base = np.stack([synth_tile(s) for s in range(8)])
+    tiles = torch.from_numpy(np.concatenate([base] * 4)).cuda()          # 32 tiles, 4 copies of 8
+    m1, h1, _ = engine1.segment(tiles, mean, std)
+    m2, h2, _ = engine1.segment(tiles, mean, std)
+    assert torch.equal(m1, m2) and torch.equal(h1, h2)                     # idempotent / deterministic
+    for k in range(1, 4):
+        assert torch.equal(m1[:8], m1[8 * k:8 * k + 8])                    # a tile's mask does not depend on its slot
+    assert (h1.sum(1) == 512 * 1024).all()
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(1)).cuda()
+    m3, h3, _ = engine1.segment(tiles[perm], mean, std)
+    assert torch.equal(m3, m1[perm]) and torch.equal(h3, h1[perm])
+    m4, _, lg = engine1.segment(tiles[:4], mean, std, want_logits=True)
+    assert torch.equal(lg.max(1)[1].byte(), m4)
