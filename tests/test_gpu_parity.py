@@ -481,3 +481,61 @@ def test_full_batch_properties(torch_mod, engine1):
     assert torch.equal(m3, m1[perm]) and torch.equal(h3, h1[perm])
     m4, _, lg = engine1.segment(tiles[:4], mean, std, want_logits=True)
     assert torch.equal(lg.max(1)[1].byte(), m4)
+
+
+def test_slide_pipeline_detect_merge_crop_segment_composite(torch_mod, engine1):
+    """BASELINE cfg 4 in miniature: synthetic slide, plug-in detector, all stages chained; stage outputs are
+    checked against the same stages run one by one"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd import pipeline
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    mean, std = FOLD_MEAN_STD[1]
+    SW, SH, mpp = 12000, 8000, 0.25
+    canvas = synth_tile(3, SH // 8, SW // 8, blobs=10)[:, :, ::-1].copy()       # RGB slide at 1/8 scale
+    truth = [(1500, 1200, 2600, 2100), (5200, 900, 6100, 2000), (8000, 5000, 9300, 6200), (3000, 5200, 3900, 6000)]
+
+    def read_region(x, y, w, h, ds):
+        # nearest sampling of the 1/8-scale canvas: deterministic stand-in for OpenSlide
+        ys = np.clip(((y + np.arange(h) * ds) / 8).astype(int), 0, canvas.shape[0] - 1)
+        xs = np.clip(((x + np.arange(w) * ds) / 8).astype(int), 0, canvas.shape[1] - 1)
+        return canvas[ys][:, xs]
+
+    state = {"i": 0}
+    plan_holder = {}
+
+    def detector(im):
+        # reports, in normalised window coordinates, the truth boxes that fall inside this window
+        p = plan_holder["plan"]
+        i, j, xs, ys = p.origins()[state["i"]]
+        state["i"] += 1
+        wx = p.window_x * p.downsample
+        out_b, out_s = [], []
+        for (x1, y1, x2, y2) in truth:
+            if x1 >= xs and y1 >= ys and x2 <= xs + wx and y2 <= ys + wx:
+                out_b.append([(y1 - ys) / wx, (x1 - xs) / wx, (y2 - ys) / wx, (x2 - xs) / wx])
+                out_s.append(0.9)
+        n = len(out_b)
+        b = np.zeros((1, max(n, 1), 4), np.float32)
+        s = np.zeros((1, max(n, 1)), np.float32)
+        if n:
+            b[0, :n], s[0, :n] = out_b, out_s
+        return b, s, np.ones_like(s), np.array([n])
+
+    from glomeruli_segmentation_amd import detect
+    plan_holder["plan"] = detect.plan_windows(SW, SH, mpp, mpp, 8.0, 2000, 0.1)
+    res = pipeline.run_slide(engine1, read_region, SW, SH, mpp, mpp, detector, mean, std)
+    assert state["i"] == len(plan_holder["plan"].origins())
+    assert len(res["boxes"]) == len(truth)                      # duplicates from overlapping windows were merged
+    for b in res["boxes"]:
+        assert any(abs(b[0] - t[0]) <= 16 and abs(b[1] - t[1]) <= 16 and abs(b[2] - t[2]) <= 16 and abs(b[3] - t[3]) <= 16 for t in truth)
+    # stage-by-stage: segment one crop alone and paste it alone
+    b = res["boxes"][0]
+    crop = np.ascontiguousarray(read_region(b[0], b[1], b[2] - b[0], b[3] - b[1], 1.0)[:, :, ::-1])
+    alone = pipeline.segment_crops(engine1, [crop], mean, std, 512, 1024)[0]
+    assert torch.equal(alone, res["masks"][0])
+    total = sum(int(m.numel()) for m in res["masks"])
+    assert int(res["counts"].sum()) == total
+    m = res["map"].cpu().numpy()
+    X0, Y0 = -(-b[0] // 8), -(-b[1] // 8)
+    sub = alone.cpu().numpy()[(Y0 * 8 - b[1])::8, (X0 * 8 - b[0])::8]
+    assert np.array_equal(m[Y0:Y0 + sub.shape[0], X0:X0 + sub.shape[1]], sub)
