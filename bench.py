@@ -204,9 +204,11 @@ def main():
             # double-buffered H2D / compute / D2H pipeline of gs_espnet_segment_host
             reps = 16
             host_tiles = torch.from_numpy(np.concatenate([tiles_np] * reps)).pin_memory()
-            eng.segment_host(host_tiles[:2 * BATCH], mean, std, batch=BATCH)          # warm-up
+            om = torch.empty((reps * BATCH, H, W), dtype=torch.uint8).pin_memory()   # caller-owned pinned outputs
+            oh = torch.zeros((reps * BATCH, 5), dtype=torch.int64).pin_memory()
+            eng.segment_host(host_tiles[:3 * BATCH], mean, std, batch=BATCH, out_masks=om[:3 * BATCH], out_hist=oh[:3 * BATCH])
             t0 = time.perf_counter()
-            hm, hh = eng.segment_host(host_tiles, mean, std, batch=BATCH)
+            hm, hh = eng.segment_host(host_tiles, mean, std, batch=BATCH, out_masks=om, out_hist=oh)
             el = time.perf_counter() - t0
             out["host_pipeline"] = {"value": round(reps * BATCH / el, 1), "unit": "patches/s", "tiles": reps * BATCH,
                                     "note": "pinned host in -> pinned host out, PCIe inclusive; masks equal the resident path: %s"

@@ -82,7 +82,7 @@ struct Model {
         hipStream_t copy = nullptr;
         hipEvent_t up = nullptr, done = nullptr, down = nullptr;
         int first = -1, count = 0;
-    } sl[2];
+    } sl[3];   // three slots: upload of batch i+1 and download of batch i-1 overlap the compute of batch i
     hipStream_t pipe_compute = nullptr;
     size_t pipe_in_bytes = 0, pipe_out_bytes = 0;
     int pipe_batch = 0;
@@ -916,7 +916,7 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
     hipStream_t compute = m.pipe_compute;
     if (m.pipe_in_bytes < in_b * batch || m.pipe_out_bytes < out_b * batch || m.pipe_batch < batch) {
         free_pipeline(m);
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 3; ++i) {
             Slot &s = sl[i];
             fail(hipHostMalloc(reinterpret_cast<void **>(&s.hin), in_b * batch, hipHostMallocDefault), "hipHostMalloc");
             fail(hipHostMalloc(reinterpret_cast<void **>(&s.hout), out_b * batch, hipHostMallocDefault), "hipHostMalloc");
@@ -933,7 +933,7 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         m.pipe_out_bytes = out_b * batch;
         m.pipe_batch = batch;
     }
-    sl[0].first = sl[1].first = -1;
+    sl[0].first = sl[1].first = sl[2].first = -1;
     auto drain = [&](Slot &s) {   // wait for the slot's masks and hand them to the caller
         if (s.first < 0 || rc != GS_OK)
             return;
@@ -945,7 +945,7 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         s.first = -1;
     };
     int slot = 0;
-    for (int first = 0; first < n_tiles && rc == GS_OK; first += batch, slot ^= 1) {
+    for (int first = 0; first < n_tiles && rc == GS_OK; first += batch, slot = (slot + 1) % 3) {
         Slot &s = sl[slot];
         drain(s);   // the slot's previous batch must have left its pinned buffers
         if (rc != GS_OK) break;
@@ -971,8 +971,8 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         s.first = first;
         s.count = cnt;
     }
-    drain(sl[slot]);
-    drain(sl[slot ^ 1]);
+    for (int k = 0; k < 3; ++k)
+        drain(sl[(slot + k) % 3]);   // oldest first
     if (rc != GS_OK)
         hipDeviceSynchronize();
     return rc;

@@ -122,7 +122,7 @@ class EspnetEngine:
                 hist.data_ptr() if want_hist else None, _stream_ptr(dev)))
         return mask, hist, logits
 
-    def segment_host(self, tiles, mean, std, batch=32, want_hist=True):
+    def segment_host(self, tiles, mean, std, batch=32, want_hist=True, out_masks=None, out_hist=None):
         """numpy uint8 [T,H,W,3] in host memory -> (masks [T,H,W], counts [T,classes]) through the
         pinned double-buffered H2D / compute / D2H pipeline of the library."""
         if isinstance(tiles, torch.Tensor):      # e.g. a pinned CPU tensor: DMA'd in place, no staging copy
@@ -131,8 +131,10 @@ class EspnetEngine:
             t, h, w, _ = tiles.shape
             in_ptr = ctypes.c_void_p(tiles.data_ptr())
             pin = tiles.is_pinned()
-            masks_t = torch.empty((t, h, w), dtype=torch.uint8, pin_memory=pin)
-            hist_t = torch.zeros((t, self.classes), dtype=torch.int64, pin_memory=pin) if want_hist else None
+            masks_t = out_masks if out_masks is not None else torch.empty((t, h, w), dtype=torch.uint8, pin_memory=pin)
+            hist_t = None
+            if want_hist:
+                hist_t = out_hist if out_hist is not None else torch.zeros((t, self.classes), dtype=torch.int64, pin_memory=pin)
             with torch.cuda.device(self.device):
                 _lib.check(self.lib.gs_espnet_segment_host(
                     self.handle, in_ptr, t, h, w, _lib.fptr3(mean), _lib.fptr3(std), batch, ctypes.c_void_p(masks_t.data_ptr()),
