@@ -250,6 +250,12 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
     m->ff = make_act(cls, cls, H1, W1, 0, 0, 0, 0);
     Act *all[] = {&m->a0, &m->inp1, &m->inp2, &m->r2, &m->bb[0], &m->bb[1], &m->bb[2], &m->a1, &m->r3,
                   &m->cc[0], &m->cc[1], &m->cc[2], &m->o2c, &m->tt, &m->ff};
+    for (Act *a : all) {   // kernels address one image with 32-bit byte offsets (buffer soffset / voffset)
+        if ((unsigned long long)a->sn * sizeof(float) >= (1ull << 31)) {
+            set_error("tile %dx%d is too large: an activation of one image exceeds 2 GiB", H, W);
+            return GS_ERR_UNSUPPORTED;
+        }
+    }
     const size_t slack = 64 * 1024;   // strips may over-read past a buffer's last row (masked lanes only)
     size_t total = 0;
     for (Act *a : all)
