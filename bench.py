@@ -75,7 +75,7 @@ def cpu_baseline(sd, tiles, mean, std):
         port.espnet_forward(x, tsd)
         reps += 1
         el = time.perf_counter() - t0
-        if el > 12.0 or reps >= 10:
+        if el > 12.0 or reps >= 40:
             break
     return {"value": round(bs * reps / el, 3), "unit": "patches/s", "cores": cores, "kind": "port",
             "sample": "%d x batch-%d forward of the 1024x512 workload through torch CPU ops (oracle/espnet_torch_port.py)"
