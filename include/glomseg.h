@@ -12,7 +12,9 @@
  * never throws; gs_last_error() gives the message of the calling thread's last failure.
  * Device pointers must belong to the HIP device that is current at the call.  A handle is bound
  * to that device and is not thread-safe; work is stream-ordered on the hipStream_t passed in
- * (NULL = the legacy default stream).
+ * (NULL = the legacy default stream).  A handle has ONE activation workspace: work submitted for it on
+ * different streams must be ordered by the caller (gs_espnet_segment_host uses streams of its own and
+ * expects every earlier call on the handle to have completed).
  */
 #ifndef GLOMSEG_H
 #define GLOMSEG_H

@@ -315,3 +315,28 @@ def test_contours_and_polygons():
     labels = [s["label"] for s in d["shapes"]]
     assert labels.count("glomerulus") == 1 and labels.count("sclerosis") == 1 and "crescent" not in labels
     assert d["imagePath"] == "x.PNG" and all(len(s["points"]) >= 3 for s in d["shapes"])
+
+
+def test_cabi_argument_and_device_errors_without_gpu(sd1):
+    """status codes + gs_last_error through the C ABI; no compute is attempted (this box has no GPU, and on a GPU
+    box the same calls stop at argument validation)"""
+    import ctypes
+    from glomeruli_segmentation_amd import _lib
+    from glomeruli_segmentation_amd.engine import pack_state_dict
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.gs_espnet_create(None, None, 0, 5, 2, 8, 0, ctypes.byref(h)) == 1          # GS_ERR_INVALID
+    assert b"null" in lib.gs_last_error()
+    blob, table = pack_state_dict(sd1)
+    rc = lib.gs_espnet_create(blob.ctypes.data_as(ctypes.c_void_p), table, len(table), 7, 2, 8, 0, ctypes.byref(h))
+    assert rc == 4 and b"classes=5" in lib.gs_last_error()                                  # GS_ERR_UNSUPPORTED
+    assert lib.gs_conv2d_nhwc(None, 1, 8, 8, 3, None, 3, 3, 4, None, 1, 1, 0, None, None) == 1
+    assert lib.gs_nms(None, None, 0, ctypes.c_float(0.5), ctypes.c_float(0.0), 10, None, None, None) == 1
+    assert lib.gs_crop_preprocess(None, 4, 4, None, None, 8, 8, None, None) == 1
+    import torch
+    if not torch.cuda.is_available():
+        rc = lib.gs_espnet_create(blob.ctypes.data_as(ctypes.c_void_p), table, len(table), 5, 2, 8, 0, ctypes.byref(h))
+        assert rc in (2, 5), rc                                                              # GS_ERR_HIP / GS_ERR_NODEVICE: loud, no fallback
+        from glomeruli_segmentation_amd.engine import EspnetEngine
+        with pytest.raises(RuntimeError):
+            EspnetEngine(sd1)
