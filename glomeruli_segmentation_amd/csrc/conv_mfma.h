@@ -74,6 +74,7 @@ struct ConvArgs {
     long long out2_sn;
     int out2_sc, out2_pitch, out2_off, out2_coff;
     unsigned out2_img_bytes;
+    int lds_tile_off;   // F_XMERGE: float offset of the per-wave LDS tiles (after the weight image)
     int stagger;   // units of 1024 cycles by which waves WAVES/2.. start late (0 = off)
     unsigned long long *stamp;   // F_X_STAMP diagnostic builds only: [wave][8] 100 MHz timestamps
     int N, H, W;   // OUTPUT size
@@ -86,6 +87,7 @@ constexpr int F_BNACT = 1;   // folded BatchNorm + PReLU on the way out
 constexpr int F_RES = 2;     // add the residual input before BN (ESP block, Model.py:211-213)
 constexpr int F_NOSTORE = 4; // skip the primary store (the block output is only consumed through out2)
 constexpr int F_DUAL = 8;
+constexpr int F_XMERGE = 256;   // TAPS == 3 only: the three horizontal taps are folded into the MFMA rows (see kernel)
 constexpr int F_X_NOLOAD = 16;  // timing experiments only (results are garbage): no activation loads in the loop
 constexpr int F_X_NOLDS = 32;   // timing experiments only: no LDS weight reads in the loop
 constexpr int F_X_NOEPI = 64;   // timing experiments only: no epilogue at all
@@ -99,10 +101,16 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     using M = Mfma<MT>;
     constexpr int KL = M::KL;
     constexpr int NSTEP = CINP / KL;
-    constexpr int NROW = NOUT1 > NOUT ? NOUT1 : NOUT;
+    constexpr int NROW = (FLAGS & F_XMERGE) ? 3 * NOUT1 : (NOUT1 > NOUT ? NOUT1 : NOUT);   // MFMA rows in use
     constexpr int COUT = NOUT1 + (NDIL - 1) * NOUT;
-    constexpr int TYN = TAPS == 9 ? 3 : 1;
+    // TAPS == 3 (with F_XMERGE) is a 3x3 convolution whose few output channels o and three horizontal taps tx
+    // are BOTH put on the MFMA rows (row = tx*NOUT1 + o): the k-loop then walks only (tap row, channel) -- a third
+    // of the k-steps, and 3*NOUT1 of MT rows busy instead of NOUT1 -- and the epilogue adds the three row groups
+    // of a pixel's neighbours through a per-wave LDS tile.  Strips overlap by two columns.
+    constexpr bool XMERGE = FLAGS & F_XMERGE;
+    constexpr int TYN = TAPS == 1 ? 1 : 3;
     constexpr int TXN = TAPS == 9 ? 3 : 1;
+    constexpr int XSTEP = XMERGE ? P * MT - 2 : P * MT;   // output pixels a strip produces
     // k-steps of one dilation in the order (row group rg = ty*NSTEP + cin-group, tx): tx fastest.  A
     // chunk is G consecutive row groups x all TXN horizontal taps = D steps, so inside a chunk the tap
     // and slot of every step are compile-time constants and only G (ty, cin-group) pairs are decoded
@@ -112,7 +120,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     constexpr int CPD = RGN / G;              // chunks per dilation
     constexpr int NCHUNK = NDIL * CPD;
     static_assert(CINP % KL == 0, "k-steps must tile");
-    static_assert(TAPS == 1 || TAPS == 9, "1x1 or 3x3");
+    static_assert(TAPS == 1 || TAPS == 9 || (TAPS == 3 && XMERGE && NDIL == 1 && STRIDE == 1 && 3 * NOUT1 <= MT), "1x1, 3x3 or row-merged 3x3");
     static_assert(RGN % G == 0, "chunk must divide the row groups of one dilation");
     static_assert(NROW <= MT, "one MFMA row block");
     constexpr int KSTR = 4;   // accumulator rows of k-group kq sit KSTR*kq above those of group 0 (both shapes)
@@ -166,11 +174,11 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         const int n = tk / tasks_per_img;
         const int rem = tk - n * tasks_per_img;
         const int y = rem / a.strips;
-        const int x0 = (rem - y * a.strips) * (P * MT);
+        const int x0 = (rem - y * a.strips) * XSTEP;
 
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.in + (long long)n * a.in_sn), 0, a.in_img_bytes, 0x00020000);
-        const int sbase = (a.in_off + y * STRIDE * a.in_pitch + x0 * STRIDE) * 4;
+        const int sbase = (a.in_off + y * STRIDE * a.in_pitch + x0 * STRIDE - (XMERGE ? 1 : 0)) * 4;
         // the wave's next task (itself when this is the last one: a harmless redundant prefetch)
         const int tn = task + tstride < t1 ? task + tstride : tk;
         const int n_n = tn / tasks_per_img;
@@ -178,7 +186,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         const int y_n = rem_n / a.strips;
         const __amdgpu_buffer_rsrc_t rsrc_n = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.in + (long long)n_n * a.in_sn), 0, a.in_img_bytes, 0x00020000);
-        const int sbase_n = (a.in_off + y_n * STRIDE * a.in_pitch + (rem_n - y_n * a.strips) * (P * MT) * STRIDE) * 4;
+        const int sbase_n = (a.in_off + y_n * STRIDE * a.in_pitch + (rem_n - y_n * a.strips) * XSTEP * STRIDE - (XMERGE ? 1 : 0)) * 4;
         const __amdgpu_buffer_rsrc_t rout =
             __builtin_amdgcn_make_buffer_rsrc(a.out + (long long)n * a.out_sn, 0, a.out_img_bytes, 0x00020000);
         const int sout = (a.out_off + y * a.out_pitch + x0) * 4;
@@ -236,7 +244,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
             const int rg = (c - di * CPD) * G + g;
             const int ty = rg / NSTEP;
             const int sidx = rg - ty * NSTEP;
-            const int toff = TAPS == 9 ? ((ty - 1) * a.in_pitch + (tx - 1)) << di : 0;
+            const int toff = TAPS == 9 ? ((ty - 1) * a.in_pitch + (tx - 1)) << di : TAPS == 3 ? (ty - 1) * a.in_pitch : 0;
             const int soff = sb + (toff + sidx * KL * a.in_sc) * 4;
             if (FLAGS & F_X_NOLOAD) {
 #pragma unroll
@@ -254,7 +262,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
             const int rg = (c - di * CPD) * G + g;
             const int ty = rg / NSTEP;
             const int sidx = rg - ty * NSTEP;
-            const int tap = TAPS == 9 ? ty * 3 + tx : 0;
+            const int tap = TAPS == 9 ? ty * 3 + tx : TAPS == 3 ? ty : 0;
             if (FLAGS & F_X_NOLDS) {
                 aq[g * TXN + tx] = __builtin_bit_cast(float, tap + sidx + lbase);
                 return;
@@ -358,6 +366,38 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
             const int di = c / CPD;
             const int nout = di == 0 ? NOUT1 : NOUT;
             const int cb = di == 0 ? 0 : NOUT1 + (di - 1) * NOUT;
+            if (XMERGE) {
+                // per-wave LDS tile [MT rows][P*MT columns]; column i is input x' = x0 - 1 + i
+                float *tile = lds + a.lds_tile_off + wid * (MT * P * MT);
+#pragma unroll
+                for (int r = 0; r < M::NACC; ++r)
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        tile[M::row(r, kq) * (P * MT) + p * MT + px] = acc[p][r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // out[o][x0 + m] = Z[0*NOUT1+o][m] + Z[1*NOUT1+o][m+1] + Z[2*NOUT1+o][m+2], m < XSTEP
+#pragma unroll
+                for (int t = 0; t < (XSTEP + 63) / 64; ++t) {
+                    const int mcol = t * 64 + lane;
+                    const bool ok = mcol < XSTEP && x0 + mcol < a.W;
+                    const int mc = mcol < XSTEP ? mcol : 0;
+#pragma unroll
+                    for (int o = 0; o < NOUT1; ++o) {
+                        float v = tile[o * (P * MT) + mc] + tile[(NOUT1 + o) * (P * MT) + mc + 1] +
+                                  tile[(2 * NOUT1 + o) * (P * MT) + mc + 2];
+                        if (BNACT) {
+                            v = v * bnp[o] + bnp[COUT + o];
+                            v = v > 0.0f ? v : bnp[2 * COUT + o] * v;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, ok ? mcol * 4 : OOB,
+                                                              o * a.out_sc * 4 + sout, 0);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();   // the tile is rewritten by this wave's next task
+                continue;
+            }
             // Branch-free epilogue: addresses are (uniform per accumulator register, in an SGPR) + (one
             // per-lane offset), so the whole slot is straight-line VALU + buffer stores.
 #pragma unroll
@@ -406,9 +446,9 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 }
 
 // number of floats of the LDS image for a configuration (weights, then 3*COUT BN/PReLU params)
-constexpr int conv_wfloats(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT, bool bn, bool dual = false)
+constexpr int conv_wfloats(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT, bool bn, bool dual = false, bool xmerge = false)
 {
-    const int nrow = NOUT1 > NOUT ? NOUT1 : NOUT;
+    const int nrow = xmerge ? 3 * NOUT1 : (NOUT1 > NOUT ? NOUT1 : NOUT);
     const int cout = NOUT1 + (NDIL - 1) * NOUT;
     const int n = NDIL * TAPS * CINP * nrow + (bn ? 3 * cout : 0) + (dual ? 3 * cout : 0);
     return (n + 3) / 4 * 4;
@@ -418,10 +458,11 @@ template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1
 gs_status launch_conv_mfma(ConvArgs a, int num_cus, hipStream_t stream)
 {
     auto kern = conv_mfma_kernel<MT, WAVES, CINP, TAPS, STRIDE, NDIL, NOUT1, NOUT, P, G, FLAGS>;
-    a.strips = cdiv(a.W, P * MT);
+    a.strips = cdiv(a.W, (FLAGS & F_XMERGE) ? P * MT - 2 : P * MT);
     a.total_tasks = a.N * a.H * a.strips;
-    a.wfloats = conv_wfloats(CINP, TAPS, NDIL, NOUT1, NOUT, FLAGS & F_BNACT, FLAGS & F_DUAL);
-    const size_t lds_bytes = (size_t)((a.wfloats + 255) / 256 * 256) * sizeof(float);   // whole 1-KiB DMA pieces
+    a.wfloats = conv_wfloats(CINP, TAPS, NDIL, NOUT1, NOUT, FLAGS & F_BNACT, FLAGS & F_DUAL, FLAGS & F_XMERGE);
+    a.lds_tile_off = (a.wfloats + 255) / 256 * 256;
+    const size_t lds_bytes = (size_t)(a.lds_tile_off + ((FLAGS & F_XMERGE) ? WAVES * MT * P * MT : 0)) * sizeof(float);   // whole 1-KiB DMA pieces (+ tiles)
     static bool attr_done = false;
     if (!attr_done) {
         GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

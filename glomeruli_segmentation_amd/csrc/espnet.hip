@@ -39,6 +39,7 @@ void set_error(const char *fmt, ...)
 #define CFG_L3_BR_W16    32, 16,  26,  9,   1,     5,   28,   25,   2, 3
 #define CFG_L3_BR_P2     32, 8,   26,  9,   1,     5,   28,   25,   2, 13
 #define CFG_DEC_CONV     16, 8,   24,  9,   1,     1,   5,    5,    8, 3
+#define CFG_DEC_CONV_XM  16, 8,   24,  3,   1,     1,   5,    5,    8, 6
 
 enum KernelId {
     K_STEM, K_POOL, K_L2_C1S, K_L2_DOWN, K_L2_C1, K_L2_ESP, K_CAT_B2, K_L3_C1S, K_L3_DOWN, K_L3_C1, K_L3_ESP,
@@ -60,7 +61,7 @@ struct Model {
     int variant = 0;   // GS_VARIANT env: kernel A/B experiments (0 = shipped configuration)
     float *dblob = nullptr;
     // offsets (floats) into dblob
-    long long w1, bn1, b1, b2, b3, wcls, br, wup3, w3c, cbr0, wcc, bncc, wup2, bnu2, wconv, wclassifier;
+    long long w1, bn1, b1, b2, b3, wcls, br, wup3, w3c, cbr0, wcc, bncc, wup2, bnu2, wconv, wconv_xm, wclassifier;
     PackedConv l2_0;
     std::vector<PackedConv> l2, l3;
     PackedConv l3_0;
@@ -557,6 +558,8 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         }
     }
     L.run(K_DEC_CONV, px1 * ((19 + CLS) * 9 * CLS * 2), [&] {
+        if (m->variant != 30)
+            return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE>(conv_args(m->a0, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
         return launch_conv_mfma<CFG_DEC_CONV, F_BNACT>(conv_args(m->a0, wb + m->wconv, m->ff, nullptr, n), m->num_cus, s);
     });
     set_stage("conv", m->ff, CLS);
@@ -713,6 +716,17 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
                         dst[((size_t)tap * npl + pl) * c + co] = w[((size_t)co * (19 + c) + wch) * 9 + tap];
                 }
             if (!fold_bn(t, "conv.bn", "conv.act", c, dst + (size_t)9 * npl * c)) return GS_ERR_INVALID;
+            // row-merged form (F_XMERGE): LDS image [ty][plane][row = tx*c + o]
+            m.wconv_xm = bb.reserve(conv_wfloats(npl, 3, 1, c, c, true, false, true));
+            float *dx = bb.data.data() + m.wconv_xm;
+            for (int ty = 0; ty < 3; ++ty)
+                for (int pl = 0; pl < npl; ++pl) {
+                    const int wch = pl < 19 ? c + pl : pl - 19;
+                    for (int tx = 0; tx < 3; ++tx)
+                        for (int co = 0; co < c; ++co)
+                            dx[((size_t)ty * npl + pl) * (3 * c) + tx * c + co] = w[((size_t)co * (19 + c) + wch) * 9 + ty * 3 + tx];
+                }
+            if (!fold_bn(t, "conv.bn", "conv.act", c, dx + (size_t)3 * npl * 3 * c)) return GS_ERR_INVALID;
         }
         if (!(w = t.get("classifier.weight", {c, c, 2, 2}))) return GS_ERR_INVALID;
         m.wclassifier = bb.push(w, (size_t)c * c * 4);
