@@ -464,7 +464,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             ConvArgs ca = conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n);
             if (m->variant == 1)
                 return launch_conv_mfma<CFG_L3_BR_W16, F_BNACT | F_RES>(ca, m->num_cus, s);
-            if (m->variant == 0)
+            if (m->variant == 0 || m->variant == 30)
                 return launch_conv_mfma<CFG_L3_BR_P2, F_BNACT | F_RES>(ca, m->num_cus, s);
             if (m->variant >= 2 && m->variant < 100)
                 ca.stagger = m->variant - 1;
