@@ -82,12 +82,17 @@ struct ConvArgs {
     int total_tasks;
 };
 
+typedef unsigned u32x3_t __attribute__((ext_vector_type(3)));
+
 // epilogue flags
 constexpr int F_BNACT = 1;   // folded BatchNorm + PReLU on the way out
 constexpr int F_RES = 2;     // add the residual input before BN (ESP block, Model.py:211-213)
 constexpr int F_NOSTORE = 4; // skip the primary store (the block output is only consumed through out2)
 constexpr int F_DUAL = 8;
 constexpr int F_XMERGE = 256;   // TAPS == 3 only: the three horizontal taps are folded into the MFMA rows (see kernel)
+constexpr int F_S2PAIR = 512;   // STRIDE == 2, TAPS == 9: the three horizontal taps of an output pixel (inputs 2x-1..2x+1)
+                                // come from one 12-byte load instead of three stride-2 dword loads, which cost the
+                                // texture-address unit 16 cycles each (4 for a unit-stride one)
 constexpr int F_X_NOLOAD = 16;  // timing experiments only (results are garbage): no activation loads in the loop
 constexpr int F_X_NOLDS = 32;   // timing experiments only: no LDS weight reads in the loop
 constexpr int F_X_NOEPI = 64;   // timing experiments only: no epilogue at all
@@ -98,6 +103,8 @@ template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1
 __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 {
     constexpr bool BNACT = FLAGS & F_BNACT, RES = FLAGS & F_RES, STORE1 = !(FLAGS & F_NOSTORE), DUAL = FLAGS & F_DUAL;
+    constexpr bool S2P = FLAGS & F_S2PAIR;
+    static_assert(!S2P || (STRIDE == 2 && TAPS == 9 && NDIL == 1), "F_S2PAIR is for the stride-2 3x3 reduce");
     using M = Mfma<MT>;
     constexpr int KL = M::KL;
     constexpr int NSTEP = CINP / KL;
@@ -166,7 +173,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 
     // operand ring (see below); it lives across tasks: the last chunk of a task refills it with the first
     // chunk of the wave's NEXT task, so only a wave's very first loads are exposed
-    float aq[D], bq[D][P];
+    float aq[D], bq[S2P ? 1 : D][P];
+    float bl[S2P ? G : 1][P][3];   // F_S2PAIR: per row group, the inputs 2x-1, 2x, 2x+1 of every pixel
 
     for (int task = t0; task < t1 || !staged; task += tstride) {
         const bool idle = task >= t1;   // a wave without work still has to help stage the weights
@@ -257,6 +265,21 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                 bq[g * TXN + tx][p] = __builtin_bit_cast(
                     float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + p * MT * STRIDE * 4, soff, 0));
         };
+        auto fetch_pair = [&](const __amdgpu_buffer_rsrc_t &rs, int sb, int c, int g) {
+            const int rg = c * G + g;
+            const int ty = rg / NSTEP;
+            const int sidx = rg - ty * NSTEP;
+            const int soff = sb + ((ty - 1) * a.in_pitch - 1 + sidx * KL * a.in_sc) * 4;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff + p * MT * STRIDE * 4, soff, 0);
+                // (copy the elements out first: __builtin_bit_cast applied directly to v[1] reads element 0 with this hipcc)
+                const unsigned e0 = v[0], e1 = v[1], e2 = v[2];
+                bl[g][p][0] = __builtin_bit_cast(float, e0);
+                bl[g][p][1] = __builtin_bit_cast(float, e1);
+                bl[g][p][2] = __builtin_bit_cast(float, e2);
+            }
+        };
         auto fetch_a = [&](int c, int g, int tx) {
             const int di = c / CPD;
             const int rg = (c - di * CPD) * G + g;
@@ -274,10 +297,15 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         // their latency overlaps the LDS fill
         if (task == t0) {
 #pragma unroll
-            for (int g = 0; g < G; ++g)
+            for (int g = 0; g < G; ++g) {
+                if (S2P) {
+                    fetch_pair(rsrc, sbase, 0, g);
+                    continue;
+                }
 #pragma unroll
                 for (int tx = 0; tx < TXN; ++tx)
                     fetch_b(rsrc, sbase, 0, g, tx);
+            }
         }
         if (!staged) {
             // weights -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR
@@ -341,8 +369,11 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                     const int u = g * TXN + tx;
 #pragma unroll
                     for (int p = 0; p < P; ++p)
-                        acc[p] = M::run(aq[u], bq[u][p], acc[p]);
-                    fetch_b(rs, sb, nx, g, tx);
+                        acc[p] = M::run(aq[u], S2P ? bl[S2P ? g : 0][p][S2P ? tx : 0] : bq[S2P ? 0 : u][p], acc[p]);
+                    if (!S2P)
+                        fetch_b(rs, sb, nx, g, tx);
+                    else if (tx == 2)
+                        fetch_pair(rs, sb, nx, g);
                     fetch_a(nx, g, tx);
                     // pin the ring order: left alone, hipcc sinks the refill loads to the end of the
                     // chunk, which shrinks the prefetch distance from D steps to a few

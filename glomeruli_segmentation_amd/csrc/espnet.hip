@@ -397,7 +397,9 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
 
     // ---- level 2 (Model.py:351-357): DownSamplerB(19,64) then p ESP blocks
     L.run(K_L2_C1S, px2 * (19 * 9 * 12 * 2), [&] {
-        return launch_conv_mfma<CFG_L2_C1S, 0>(conv_args(m->a0, wb + m->l2_0.c1, m->r2, nullptr, n), m->num_cus, s);
+        if (m->variant == 41)
+            return launch_conv_mfma<CFG_L2_C1S, 0>(conv_args(m->a0, wb + m->l2_0.c1, m->r2, nullptr, n), m->num_cus, s);
+        return launch_conv_mfma<CFG_L2_C1S, F_S2PAIR>(conv_args(m->a0, wb + m->l2_0.c1, m->r2, nullptr, n), m->num_cus, s);
     });
     // b2 = BR(131) over cat([output1, output1_0, inp2]) (Model.py:359) is fused into its producers:
     // the down-sampler stores output1_0 twice (raw for the ESP blocks, b2-normalised into planes
@@ -448,7 +450,9 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
 
     // ---- level 3 (Model.py:361-366)
     L.run(K_L3_C1S, px3 * (131 * 9 * 25 * 2), [&] {
-        return launch_conv_mfma<CFG_L3_C1S, 0>(conv_args(m->a1, wb + m->l3_0.c1, m->r3, nullptr, n), m->num_cus, s);
+        if (m->variant == 41)
+            return launch_conv_mfma<CFG_L3_C1S, 0>(conv_args(m->a1, wb + m->l3_0.c1, m->r3, nullptr, n), m->num_cus, s);
+        return launch_conv_mfma<CFG_L3_C1S, F_S2PAIR>(conv_args(m->a1, wb + m->l3_0.c1, m->r3, nullptr, n), m->num_cus, s);
     });
     L.run(K_L3_DOWN, px3 * (25 * 9 * 128 * 2), [&] {
         return launch_conv_mfma<CFG_L3_BR, F_BNACT>(conv_args(m->r3, wb + m->l3_0.br, m->cc[0], nullptr, n), m->num_cus, s);
