@@ -83,6 +83,55 @@ struct ConvArgs {
 };
 
 typedef unsigned u32x3_t __attribute__((ext_vector_type(3)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// N consecutive floats through one (N = 2, 4) or two (N = 8) buffer instructions.  Elements are copied out
+// before the bit cast: __builtin_bit_cast applied directly to v[j] reads element 0 with this hipcc.
+template <int N>
+__device__ __forceinline__ void buf_load_vec(const __amdgpu_buffer_rsrc_t &rs, int voff, int soff, float *dst)
+{
+    if constexpr (N == 2) {
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+        const unsigned e0 = v[0], e1 = v[1];
+        dst[0] = __builtin_bit_cast(float, e0);
+        dst[1] = __builtin_bit_cast(float, e1);
+    } else {
+        static_assert(N == 4 || N == 8, "vector width");
+#pragma unroll
+        for (int h = 0; h < N / 4; ++h) {
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * h, soff, 0);
+            const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+            dst[4 * h + 0] = __builtin_bit_cast(float, e0);
+            dst[4 * h + 1] = __builtin_bit_cast(float, e1);
+            dst[4 * h + 2] = __builtin_bit_cast(float, e2);
+            dst[4 * h + 3] = __builtin_bit_cast(float, e3);
+        }
+    }
+}
+// The uniform part of the address is added into the per-lane offset and the instruction's soffset is the
+// constant 0: with an SGPR soffset hipcc assumes that a >64-bit buffer store has no write-data hazard and lets
+// the next VALU instruction overwrite the data registers, and on gfx950 the store then sometimes writes the new
+// register contents (seen as lane offsets appearing in the output).
+template <int N>
+__device__ __forceinline__ void buf_store_vec(const __amdgpu_buffer_rsrc_t &rs, int voff, const float *src)
+{
+    if constexpr (N == 2) {
+        u32x2_t v;
+        v[0] = __builtin_bit_cast(unsigned, src[0]);
+        v[1] = __builtin_bit_cast(unsigned, src[1]);
+        __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff, 0, 0);
+    } else {
+#pragma unroll
+        for (int h = 0; h < N / 4; ++h) {
+            u32x4_t v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[j] = __builtin_bit_cast(unsigned, src[4 * h + j]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + 16 * h, 0, 0);
+        }
+    }
+}
 
 // epilogue flags
 constexpr int F_BNACT = 1;   // folded BatchNorm + PReLU on the way out
@@ -93,6 +142,8 @@ constexpr int F_XMERGE = 256;   // TAPS == 3 only: the three horizontal taps are
 constexpr int F_S2PAIR = 512;   // STRIDE == 2, TAPS == 9: the three horizontal taps of an output pixel (inputs 2x-1..2x+1)
                                 // come from one 12-byte load instead of three stride-2 dword loads, which cost the
                                 // texture-address unit 16 cycles each (4 for a unit-stride one)
+constexpr int F_VEC = 1024;  // lane j owns P CONSECUTIVE pixels (instead of pixel j of P runs): operands, residual and
+                             // results move as 8/16-byte accesses.  Needs STRIDE == 1, W % P == 0, P in {2, 4, 8}.
 constexpr int F_X_NOLOAD = 16;  // timing experiments only (results are garbage): no activation loads in the loop
 constexpr int F_X_NOLDS = 32;   // timing experiments only: no LDS weight reads in the loop
 constexpr int F_X_NOEPI = 64;   // timing experiments only: no epilogue at all
@@ -104,6 +155,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 {
     constexpr bool BNACT = FLAGS & F_BNACT, RES = FLAGS & F_RES, STORE1 = !(FLAGS & F_NOSTORE), DUAL = FLAGS & F_DUAL;
     constexpr bool S2P = FLAGS & F_S2PAIR;
+    constexpr bool VEC = FLAGS & F_VEC;
+    static_assert(!VEC || (STRIDE == 1 && (P == 2 || P == 4 || P == 8)), "F_VEC needs unit stride and P in {2,4,8}");
     static_assert(!S2P || (STRIDE == 2 && TAPS == 9 && NDIL == 1), "F_S2PAIR is for the stride-2 3x3 reduce");
     using M = Mfma<MT>;
     constexpr int KL = M::KL;
@@ -142,11 +195,13 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane % MT, kq = lane / MT;
-    const int voff = (kq * a.in_sc + px * STRIDE) * 4;
+    // pixel owned by (lane, p): x0 + p*MT + px (run form) or x0 + px*P + p (F_VEC: P consecutive pixels per lane)
+    const int xl = VEC ? px * P : px;
+    const int voff = (kq * a.in_sc + xl * STRIDE) * 4;
     const int lbase = kq * NROW + (px < NROW ? px : NROW - 1);
-    const int vout = (kq * KSTR * a.out_sc + px) * 4;
-    const int vres = RES ? (kq * KSTR * a.res_sc + px) * 4 : 0;
-    const int vout2 = DUAL ? (kq * KSTR * a.out2_sc + px) * 4 : 0;
+    const int vout = (kq * KSTR * a.out_sc + xl) * 4;
+    const int vres = RES ? (kq * KSTR * a.res_sc + xl) * 4 : 0;
+    const int vout2 = DUAL ? (kq * KSTR * a.out2_sc + xl) * 4 : 0;
 
     // Task order is (image, row, strip).  Workgroups that share an XCD (equal blockIdx % 8 under
     // round-robin dispatch: a speed assumption only) own one contiguous eighth of the tasks, and inside
@@ -213,10 +268,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         int vo[P], vr[P], vo2[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const bool xok = x0 + p * MT + px < a.W;
-            vo[p] = xok ? vout + p * MT * 4 : OOB;
-            vr[p] = xok ? vres + p * MT * 4 : OOB;
-            vo2[p] = xok ? vout2 + p * MT * 4 : OOB;
+            const bool xok = x0 + (VEC ? xl : p * MT + px) < a.W;   // F_VEC: W % P == 0, a lane's pixels are all in or all out
+            vo[p] = xok ? vout + (VEC ? 0 : p * MT * 4) : OOB;
+            vr[p] = xok ? vres + (VEC ? 0 : p * MT * 4) : OOB;
+            vo2[p] = xok ? vout2 + (VEC ? 0 : p * MT * 4) : OOB;
         }
         // The residual (block input) values of a whole concat slot live in dedicated registers and are
         // requested a full dilation ahead of the epilogue that adds them: fetched next to the store,
@@ -232,6 +287,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                 const int ch0 = M::row(r, 0);
                 const bool live = ch0 + kq * KSTR < nout;
                 const int sr = (cb + ch0) * a.res_sc * 4 + sres;
+                if (VEC) {
+                    buf_load_vec<P>(rres, live ? vr[0] : OOB, sr, resv[RES ? r : 0]);
+                    continue;
+                }
 #pragma unroll
                 for (int p = 0; p < P; ++p)
                     resv[RES ? r : 0][p] = __builtin_bit_cast(
@@ -258,6 +317,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
 #pragma unroll
                 for (int p = 0; p < P; ++p)
                     bq[g * TXN + tx][p] = __builtin_bit_cast(float, soff + p);
+                return;
+            }
+            if (VEC) {
+                buf_load_vec<P>(rs, voff, soff, bq[S2P ? 0 : g * TXN + tx]);
                 return;
             }
 #pragma unroll
@@ -404,7 +467,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                 for (int r = 0; r < M::NACC; ++r)
 #pragma unroll
                     for (int p = 0; p < P; ++p)
-                        tile[M::row(r, kq) * (P * MT) + p * MT + px] = acc[p][r];
+                        tile[M::row(r, kq) * (P * MT) + (VEC ? xl + p : p * MT + px)] = acc[p][r];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -449,6 +512,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                         alpha2 = bp[5 * COUT];
                     }
                 }
+                float o1[P], o2[P];
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     float v = acc[p][r];
@@ -458,15 +522,22 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                         v = v * scale + shift;
                         v = v > 0.0f ? v : alpha * v;
                     }
-                    if (STORE1)
+                    o1[p] = v;
+                    if (!VEC && STORE1)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, live ? vo[p] : OOB, so, 0);
                     if (DUAL) {
                         float v2 = v * scale2 + shift2;
                         v2 = v2 > 0.0f ? v2 : alpha2 * v2;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2), rout2,
-                                                              live ? vo2[p] : OOB, so2, 0);
+                        o2[p] = v2;
+                        if (!VEC)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2), rout2,
+                                                                  live ? vo2[p] : OOB, so2, 0);
                     }
                 }
+                if (VEC && STORE1)
+                    buf_store_vec<P>(rout, live ? vo[0] + so : OOB, o1);
+                if (VEC && DUAL)
+                    buf_store_vec<P>(rout2, live ? vo2[0] + so2 : OOB, o2);
             }
             if (di + 1 < NDIL)
                 prefetch_res(di + 1);

@@ -41,6 +41,16 @@ void set_error(const char *fmt, ...)
 #define CFG_DEC_CONV     16, 8,   24,  9,   1,     1,   5,    5,    8, 3
 #define CFG_DEC_CONV_XM  16, 8,   24,  3,   1,     1,   5,    5,    8, 6
 
+// every unit-stride conv launch exists in two pixel mappings; the vector one needs the output width to be a multiple of P
+#define LAUNCH_CONV(CFG, PVAL, FLAGS, ARGS)                                                                   \
+    ((ARGS).W % (PVAL) == 0 && !getenv_flag("GS_NO_VEC") ? launch_conv_mfma<CFG, (FLAGS) | F_VEC>((ARGS), m->num_cus, s) \
+                                                          : launch_conv_mfma<CFG, (FLAGS)>((ARGS), m->num_cus, s))
+static bool getenv_flag(const char *name)
+{
+    const char *e = std::getenv(name);
+    return e && std::atoi(e) != 0;
+}
+
 enum KernelId {
     K_STEM, K_POOL, K_L2_C1S, K_L2_DOWN, K_L2_C1, K_L2_ESP, K_CAT_B2, K_L3_C1S, K_L3_DOWN, K_L3_C1, K_L3_ESP,
     K_DEC1, K_DEC2, K_DEC3, K_DEC_CONV, K_DEC4, K_COUNT
@@ -417,9 +427,12 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     };
     const bool fuse_b2 = m->p > 0;
     L.run(K_L2_DOWN, px2 * (12 * 9 * 64 * 2), [&] {
-        if (fuse_b2)
-            return launch_conv_mfma<CFG_L2_BR, F_BNACT | F_DUAL>(with_dual(conv_args(m->r2, wb + m->l2_0.br, m->bb[0], nullptr, n), 64), m->num_cus, s);
-        return launch_conv_mfma<CFG_L2_BR, F_BNACT>(conv_args(m->r2, wb + m->l2_0.br, m->bb[0], nullptr, n), m->num_cus, s);
+        ConvArgs ca = conv_args(m->r2, wb + m->l2_0.br, m->bb[0], nullptr, n);
+        if (fuse_b2) {
+            ca = with_dual(ca, 64);
+            return LAUNCH_CONV(CFG_L2_BR, 8, F_BNACT | F_DUAL, ca);
+        }
+        return LAUNCH_CONV(CFG_L2_BR, 8, F_BNACT, ca);
     });
     set_stage("level2_0", m->bb[0], 64);
     int cur2 = 0;
@@ -427,13 +440,16 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         const int nxt = cur2 == 1 ? 2 : 1;
         const bool last = i == m->p - 1;
         L.run(K_L2_C1, px2 * (64 * 12 * 2), [&] {
-            return launch_conv_mfma<CFG_L2_C1, 0>(conv_args(m->bb[cur2], wb + m->l2[i].c1, m->r2, nullptr, n), m->num_cus, s);
+            ConvArgs ca = conv_args(m->bb[cur2], wb + m->l2[i].c1, m->r2, nullptr, n);
+            return launch_conv_mfma<CFG_L2_C1, 0>(ca, m->num_cus, s);   // 1x1: the run mapping measured no slower
         });
         L.run(K_L2_ESP, px2 * (12 * 9 * 64 * 2), [&] {
-            if (last)
-                return launch_conv_mfma<CFG_L2_BR, F_BNACT | F_RES | F_NOSTORE | F_DUAL>(
-                    with_dual(conv_args(m->r2, wb + m->l2[i].br, m->bb[nxt], &m->bb[cur2], n), 0), m->num_cus, s);
-            return launch_conv_mfma<CFG_L2_BR, F_BNACT | F_RES>(conv_args(m->r2, wb + m->l2[i].br, m->bb[nxt], &m->bb[cur2], n), m->num_cus, s);
+            ConvArgs ca = conv_args(m->r2, wb + m->l2[i].br, m->bb[nxt], &m->bb[cur2], n);
+            if (last) {
+                ca = with_dual(ca, 0);
+                return LAUNCH_CONV(CFG_L2_BR, 8, F_BNACT | F_RES | F_NOSTORE | F_DUAL, ca);
+            }
+            return LAUNCH_CONV(CFG_L2_BR, 8, F_BNACT | F_RES, ca);
         });
         cur2 = nxt;
         if (!last)
@@ -455,21 +471,28 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         return launch_conv_mfma<CFG_L3_C1S, F_S2PAIR>(conv_args(m->a1, wb + m->l3_0.c1, m->r3, nullptr, n), m->num_cus, s);
     });
     L.run(K_L3_DOWN, px3 * (25 * 9 * 128 * 2), [&] {
-        return launch_conv_mfma<CFG_L3_BR, F_BNACT>(conv_args(m->r3, wb + m->l3_0.br, m->cc[0], nullptr, n), m->num_cus, s);
+        ConvArgs ca = conv_args(m->r3, wb + m->l3_0.br, m->cc[0], nullptr, n);
+        return LAUNCH_CONV(CFG_L3_BR, 4, F_BNACT, ca);
     });
     set_stage("level3_0", m->cc[0], 128);
     int cur3 = 0;
     for (int i = 0; i < m->q; ++i) {
         const int nxt = cur3 == 1 ? 2 : 1;
         L.run(K_L3_C1, px3 * (128 * 25 * 2), [&] {
-            return launch_conv_mfma<CFG_L3_C1, 0>(conv_args(m->cc[cur3], wb + m->l3[i].c1, m->r3, nullptr, n), m->num_cus, s);
+            ConvArgs ca = conv_args(m->cc[cur3], wb + m->l3[i].c1, m->r3, nullptr, n);
+            return launch_conv_mfma<CFG_L3_C1, 0>(ca, m->num_cus, s);
         });
         L.run(K_L3_ESP, px3 * (25 * 9 * 128 * 2), [&] {
             ConvArgs ca = conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n);
             if (m->variant == 1)
                 return launch_conv_mfma<CFG_L3_BR_W16, F_BNACT | F_RES>(ca, m->num_cus, s);
-            if (m->variant == 0 || m->variant == 30)
+            if (m->variant == 0 || m->variant == 30) {
+                // four consecutive pixels per lane and 16-byte accesses when the width allows it (0.170 ms per
+                // launch at batch 32), else the two-run mapping with its deeper ring (0.175 ms)
+                if (ca.W % 4 == 0 && !getenv_flag("GS_NO_VEC"))
+                    return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC>(ca, m->num_cus, s);
                 return launch_conv_mfma<CFG_L3_BR_P2, F_BNACT | F_RES>(ca, m->num_cus, s);
+            }
             if (m->variant >= 2 && m->variant < 100)
                 ca.stagger = m->variant - 1;
             if (m->variant == 105) {
