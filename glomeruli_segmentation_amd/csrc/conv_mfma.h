@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                                   tile[(2 * NOUT1 + o) * (P * MT) + mc + 2];
                         if (BNACT) {
                             v = v * bnp[o] + bnp[COUT + o];
-                            v = v > 0.0f ? v : bnp[2 * COUT + o] * v;
+                            v = fmaxf(v, 0.0f) + bnp[2 * COUT + o] * fminf(v, 0.0f);   // PReLU without a branch around the alpha read
                         }
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, ok ? mcol * 4 : OOB,
                                                               o * a.out_sc * 4 + sout, 0);
