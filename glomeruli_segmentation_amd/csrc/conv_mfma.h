@@ -76,6 +76,7 @@ struct ConvArgs {
     unsigned out2_img_bytes;
     int lds_tile_off;   // F_XMERGE: float offset of the per-wave LDS tiles (after the weight image)
     int stagger;   // units of 1024 cycles by which waves WAVES/2.. start late (0 = off)
+    int prio_mode; // wave priority of the two halves of a workgroup: 0 alternates per dilation, 1 per task, 2 off, 3 fixed
     unsigned long long *stamp;   // F_X_STAMP diagnostic builds only: [wave][8] 100 MHz timestamps
     int N, H, W;   // OUTPUT size
     int strips;    // pixel strips per output row
@@ -147,6 +148,8 @@ constexpr int F_VEC = 1024;  // lane j owns P CONSECUTIVE pixels (instead of pix
 constexpr int F_X_NOLOAD = 16;  // timing experiments only (results are garbage): no activation loads in the loop
 constexpr int F_X_NOLDS = 32;   // timing experiments only: no LDS weight reads in the loop
 constexpr int F_X_NOEPI = 64;   // timing experiments only: no epilogue at all
+constexpr int F_X_STAMP2 = 4096;   // diagnostic build: [wave][64] stamps of the wave's first task: 0 start, 2+2c after the MFMA
+                                   // steps of chunk c, 3+2c after the epilogue that follows chunk c
 constexpr int F_X_STAMP = 128;  // diagnostic build: per-wave s_memrealtime stamps into a.stamp (start, staged, per-dilation, end)    // second store into a concat buffer through a second BN+PReLU: the b2 / b3
                              // "BR over a torch.cat" stages (Model.py:359) fused into the producers
 
@@ -391,7 +394,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         // optional stagger: the two waves that share a SIMD run the same program on equal-sized tasks
         // and would otherwise reach their epilogues (no MFMA issue) together
         if (a.stagger > 0 && task == t0) {
-            const int ph = (blockIdx.x * 3 + wid * 5) & 7;   // 8 phases spread over waves and workgroups
+            const int ph = wid >= WAVES / 2 ? 1 : 0;   // the second wave of every SIMD starts late
             for (int z = 0; z < a.stagger * ph; ++z)
                 __builtin_amdgcn_s_sleep(16);
         }
@@ -404,9 +407,18 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         }
 
         prefetch_res(0);
+        if (a.prio_mode == 1) {
+            if ((((task - t0) / tstride) + (wid >= WAVES / 2 ? 1 : 0)) & 1)
+                __builtin_amdgcn_s_setprio(1);
+            else
+                __builtin_amdgcn_s_setprio(0);
+        } else if (a.prio_mode == 3 && task == t0) {
+            if (wid >= WAVES / 2)
+                __builtin_amdgcn_s_setprio(1);
+        }
 
         for (int c = 0; c < NCHUNK; ++c) {
-            if (NDIL > 1 && c % CPD == 0) {
+            if (NDIL > 1 && c % CPD == 0 && a.prio_mode == 0) {
                 // The two waves of a SIMD run the same program; arbitration prefers the older one, which
                 // then finishes its task ~20 % earlier and leaves its partner alone on the pipe.
                 // Alternating static priority per dilation keeps the pair level.
@@ -442,6 +454,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                     // chunk, which shrinks the prefetch distance from D steps to a few
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            if ((FLAGS & F_X_STAMP2) && lane == 0 && task == t0)
+                a.stamp[wg * 64 + 2 + 2 * c] = __builtin_amdgcn_s_memrealtime();
             if ((c + 1) % CPD != 0)
                 continue;
             if (FLAGS & F_X_NOEPI) {
@@ -496,6 +510,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
             // per-lane offset), so the whole slot is straight-line VALU + buffer stores.
 #pragma unroll
             for (int r = 0; r < M::NACC; ++r) {
+                if ((FLAGS & F_X_STAMP2) && lane == 0 && task == t0 && r < 4)
+                    a.stamp[wg * 64 + 34 + di * 4 + r] = __builtin_amdgcn_s_memrealtime();
                 const int ch0 = M::row(r, 0);   // channel held by k-group 0; group kq holds ch0 + kq*KSTR
                 const bool live = ch0 + kq * KSTR < nout;
                 const int so = (cb + ch0) * a.out_sc * 4 + sout;
@@ -543,6 +559,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                 prefetch_res(di + 1);
             if ((FLAGS & F_X_STAMP) && lane == 0 && task == t0)
                 a.stamp[wg * 8 + 2 + di] = __builtin_amdgcn_s_memrealtime();
+            if ((FLAGS & F_X_STAMP2) && lane == 0 && task == t0)
+                a.stamp[wg * 64 + 3 + 2 * c] = __builtin_amdgcn_s_memrealtime();
         }
     }
 }
@@ -562,6 +580,11 @@ gs_status launch_conv_mfma(ConvArgs a, int num_cus, hipStream_t stream)
     auto kern = conv_mfma_kernel<MT, WAVES, CINP, TAPS, STRIDE, NDIL, NOUT1, NOUT, P, G, FLAGS>;
     a.strips = cdiv(a.W, (FLAGS & F_XMERGE) ? P * MT - 2 : P * MT);
     a.total_tasks = a.N * a.H * a.strips;
+    a.prio_mode = 1;   // measured on the level-3 branch kernel: per dilation 0.171 ms, per task 0.167, off 0.168, fixed 0.166
+    if (const char *e = std::getenv("GS_PRIO"))
+        a.prio_mode = std::atoi(e);
+    if (const char *e = std::getenv("GS_STAGGER"))
+        a.stagger = std::atoi(e);
     a.wfloats = conv_wfloats(CINP, TAPS, NDIL, NOUT1, NOUT, FLAGS & F_BNACT, FLAGS & F_DUAL, FLAGS & F_XMERGE);
     a.lds_tile_off = (a.wfloats + 255) / 256 * 256;
     const size_t lds_bytes = (size_t)(a.lds_tile_off + ((FLAGS & F_XMERGE) ? WAVES * MT * P * MT : 0)) * sizeof(float);   // whole 1-KiB DMA pieces (+ tiles)

@@ -33,6 +33,7 @@ void set_error(const char *fmt, ...)
 #define CFG_L2_C1S       16, 8,   20,  9,   2,     1,   12,   12,   L2P, 3
 #define CFG_L2_C1        16, 8,   64,  1,   1,     1,   12,   12,   L2P, 8
 #define CFG_L2_BR        16, 8,   12,  9,   1,     5,   16,   12,   L2P, 3
+#define CFG_L2_BR_P4     16, 8,   12,  9,   1,     5,   16,   12,   4, 3   // shipped: <= 128 VGPRs, four waves per SIMD
 #define CFG_L3_C1S       32, 8,   132, 9,   2,     1,   25,   25,   4, 6
 #define CFG_L3_C1        32, 8,   128, 1,   1,     1,   25,   25,   4, 16
 #define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 3
@@ -41,16 +42,22 @@ void set_error(const char *fmt, ...)
 #define CFG_DEC_CONV     16, 8,   24,  9,   1,     1,   5,    5,    8, 3
 #define CFG_DEC_CONV_XM  16, 8,   24,  3,   1,     1,   5,    5,    8, 6
 
-// every unit-stride conv launch exists in two pixel mappings; the vector one needs the output width to be a multiple of P
-#define LAUNCH_CONV(CFG, PVAL, FLAGS, ARGS)                                                                   \
-    ((ARGS).W % (PVAL) == 0 && !getenv_flag("GS_NO_VEC") ? launch_conv_mfma<CFG, (FLAGS) | F_VEC>((ARGS), m->num_cus, s) \
-                                                          : launch_conv_mfma<CFG, (FLAGS)>((ARGS), m->num_cus, s))
 static bool getenv_flag(const char *name)
 {
     const char *e = std::getenv(name);
     return e && std::atoi(e) != 0;
 }
 
+// Every unit-stride conv launch exists in two pixel mappings; the vector one (F_VEC) needs the output width to be a
+// multiple of P (the 9th configuration parameter).
+template <int FLAGS, int... C>
+static gs_status launch_vec(const ConvArgs &ca, int num_cus, hipStream_t s)
+{
+    constexpr int cfg[] = {C...};
+    if (ca.W % cfg[8] == 0 && !getenv_flag("GS_NO_VEC"))
+        return launch_conv_mfma<C..., FLAGS | F_VEC>(ca, num_cus, s);
+    return launch_conv_mfma<C..., FLAGS>(ca, num_cus, s);
+}
 enum KernelId {
     K_STEM, K_POOL, K_L2_C1S, K_L2_DOWN, K_L2_C1, K_L2_ESP, K_CAT_B2, K_L3_C1S, K_L3_DOWN, K_L3_C1, K_L3_ESP,
     K_DEC1, K_DEC2, K_DEC3, K_DEC_CONV, K_DEC4, K_COUNT
@@ -430,9 +437,10 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         ConvArgs ca = conv_args(m->r2, wb + m->l2_0.br, m->bb[0], nullptr, n);
         if (fuse_b2) {
             ca = with_dual(ca, 64);
-            return LAUNCH_CONV(CFG_L2_BR, 8, F_BNACT | F_DUAL, ca);
+            if (m->variant == 150) return launch_vec<F_BNACT | F_DUAL, CFG_L2_BR>(ca, m->num_cus, s);
+            return launch_vec<F_BNACT | F_DUAL, CFG_L2_BR_P4>(ca, m->num_cus, s);
         }
-        return LAUNCH_CONV(CFG_L2_BR, 8, F_BNACT, ca);
+        return launch_vec<F_BNACT, CFG_L2_BR_P4>(ca, m->num_cus, s);
     });
     set_stage("level2_0", m->bb[0], 64);
     int cur2 = 0;
@@ -445,11 +453,38 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         });
         L.run(K_L2_ESP, px2 * (12 * 9 * 64 * 2), [&] {
             ConvArgs ca = conv_args(m->r2, wb + m->l2[i].br, m->bb[nxt], &m->bb[cur2], n);
+            // timing-only diagnostics of the level-2 branch kernel (results are wrong by construction for 141..143)
+            if (m->variant >= 140 && m->variant <= 143) {   // per-chunk stamps of each wave's first task -> gpurun_out/stamps2.txt
+                static unsigned long long *stamp2 = nullptr;
+                const size_t nst = 8192 * 64;
+                if (!stamp2) hipMalloc(reinterpret_cast<void **>(&stamp2), nst * 8);
+                hipMemsetAsync(stamp2, 0, nst * 8, s);
+                ca.stamp = stamp2;
+                gs_status st = m->variant == 140   ? launch_conv_mfma<CFG_L2_BR, F_BNACT | F_RES | F_VEC | F_X_STAMP2>(ca, m->num_cus, s)
+                               : m->variant == 141 ? launch_conv_mfma<CFG_L2_BR, F_BNACT | F_RES | F_VEC | F_X_NOEPI | F_X_STAMP2>(ca, m->num_cus, s)
+                               : m->variant == 142 ? launch_conv_mfma<CFG_L2_BR, F_BNACT | F_VEC | F_X_STAMP2>(ca, m->num_cus, s)
+                                                   : launch_conv_mfma<CFG_L2_BR, F_VEC | F_X_STAMP2>(ca, m->num_cus, s);
+                if (!last) {
+                    std::vector<unsigned long long> h(nst);
+                    hipMemcpy(h.data(), stamp2, nst * 8, hipMemcpyDeviceToHost);
+                    if (FILE *f = std::fopen("gpurun_out/stamps2.txt", "w")) {
+                        for (size_t w = 0; w < 8192; ++w) {
+                            if (!h[w * 64 + 2]) continue;
+                            for (int k = 0; k < 54; ++k) std::fprintf(f, "%llu ", h[w * 64 + k]);
+                            std::fprintf(f, "\n");
+                        }
+                        std::fclose(f);
+                    }
+                }
+                return st;
+            }
             if (last) {
                 ca = with_dual(ca, 0);
-                return LAUNCH_CONV(CFG_L2_BR, 8, F_BNACT | F_RES | F_NOSTORE | F_DUAL, ca);
+                if (m->variant == 150) return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL, CFG_L2_BR>(ca, m->num_cus, s);
+                return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL, CFG_L2_BR_P4>(ca, m->num_cus, s);
             }
-            return LAUNCH_CONV(CFG_L2_BR, 8, F_BNACT | F_RES, ca);
+            if (m->variant == 150) return launch_vec<F_BNACT | F_RES, CFG_L2_BR>(ca, m->num_cus, s);
+            return launch_vec<F_BNACT | F_RES, CFG_L2_BR_P4>(ca, m->num_cus, s);
         });
         cur2 = nxt;
         if (!last)
@@ -472,7 +507,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     });
     L.run(K_L3_DOWN, px3 * (25 * 9 * 128 * 2), [&] {
         ConvArgs ca = conv_args(m->r3, wb + m->l3_0.br, m->cc[0], nullptr, n);
-        return LAUNCH_CONV(CFG_L3_BR, 4, F_BNACT, ca);
+        return launch_vec<F_BNACT, CFG_L3_BR>(ca, m->num_cus, s);
     });
     set_stage("level3_0", m->cc[0], 128);
     int cur3 = 0;
@@ -520,6 +555,10 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
                 return launch_conv_mfma<CFG_L3_BR, F_BNACT>(ca, m->num_cus, s);
             if (m->variant == 101)
                 return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI>(ca, m->num_cus, s);
+            if (m->variant == 108)
+                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | F_X_NOEPI>(ca, m->num_cus, s);
+            if (m->variant == 109)   // stores, no residual
+                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_VEC>(ca, m->num_cus, s);
             if (m->variant == 102)
                 return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI | F_X_NOLOAD>(ca, m->num_cus, s);
             if (m->variant == 103)
