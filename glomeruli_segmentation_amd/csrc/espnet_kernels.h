@@ -39,6 +39,13 @@ __device__ __forceinline__ float bn_prelu(float v, const float *bnp, int C, int 
 {
     return prelu(v * bnp[c] + bnp[C + c], bnp[2 * C + c]);
 }
+// select form for the stem, where it measured faster (0.122 vs 0.131 ms): that kernel is short of scalar-load
+// bandwidth (432 weights per wave) and the branch skips the alpha loads of all-positive waves
+__device__ __forceinline__ float bn_prelu_sel(float v, const float *bnp, int C, int c)
+{
+    v = v * bnp[c] + bnp[C + c];
+    return v > 0.0f ? v : bnp[2 * C + c] * v;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Stem: normalise -> level1 CBR(3,16,3,2) -> sample1 avg-pool -> cat -> b1 BR(19)
@@ -117,8 +124,8 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
                     s = fmaf(a.w1[((o * 3 + c) * 3 + ky) * 3 + kx], v[c][ky][kx], s);
-        s = bn_prelu(s, a.bn1, 16, o);
-        outv[o] = bn_prelu(s, a.b1, 19, o);
+        s = bn_prelu_sel(s, a.bn1, 16, o);
+        outv[o] = bn_prelu_sel(s, a.b1, 19, o);
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -130,7 +137,7 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
                 s += v[c][ky][kx];
         s = s / 9.0f;   // count_include_pad=True
         poolv[c] = s;
-        outv[16 + c] = bn_prelu(s, a.b1, 19, 16 + c);
+        outv[16 + c] = bn_prelu_sel(s, a.b1, 19, 16 + c);
     }
 #pragma unroll
     for (int o = 0; o < 19; ++o)
