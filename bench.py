@@ -104,15 +104,32 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # rehearsal knobs for a one-GPU box (never set by the driver): GS_BENCH_BACKEND=gloo GS_BENCH_ONE_GPU=1 run
+    # the N-rank control flow with every rank on device 0 and the two tiny reductions staged through host memory
+    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("GS_BENCH_ONE_GPU") == "1":
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+
+    def all_reduce(t, op=None):
+        kw = {} if op is None else {"op": op}
+        if backend == "nccl":
+            dist.all_reduce(t, **kw)
+        else:
+            tc = t.cpu()
+            dist.all_reduce(tc, **kw)
+            t.copy_(tc)
 
     sd = load_weights()
     mean, std = FOLD_MEAN_STD[1]
@@ -141,7 +158,7 @@ def main():
         for _ in range(steps):
             step()
         if dist is not None:
-            dist.all_reduce(totals)        # the one exchange: slide-level per-class pixel totals
+            all_reduce(totals)             # the one exchange: slide-level per-class pixel totals
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -158,7 +175,7 @@ def main():
 
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     if rank == 0:

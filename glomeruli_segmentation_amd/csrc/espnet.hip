@@ -520,7 +520,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         L.run(K_L3_ESP, px3 * (25 * 9 * 128 * 2), [&] {
             ConvArgs ca = conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n);
             if (m->variant == 1)
-                return launch_conv_mfma<CFG_L3_BR_W16, F_BNACT | F_RES>(ca, m->num_cus, s);
+                return launch_conv_mfma<CFG_L3_BR_W16, F_BNACT | F_RES | F_VEC>(ca, m->num_cus, s);
             if (m->variant == 0 || m->variant == 30) {
                 // four consecutive pixels per lane and 16-byte accesses when the width allows it (0.170 ms per
                 // launch at batch 32), else the two-run mapping with its deeper ring (0.175 ms)
