@@ -71,6 +71,120 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_kernel(const ConvNhwcArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv2d NHWC, tiled form for cin % 8 == 0 (every backbone layer but the first).
+// A wave owns 64 output pixels x 64 output channels (2 x 2 MFMA tiles, 64 accumulator registers); a workgroup is
+// four such waves along the pixel axis.  K walks (tap, 8-channel chunk): per chunk a lane fetches FOUR consecutive
+// input channels of each of its two pixels with one 16-byte load (k-group kq takes channels c+4kq..c+4kq+3, so
+// element s of the load is the lane's operand of k-step s) and the four weight rows it needs for both channel
+// tiles as coalesced dword loads (the weight tensor is a few hundred KB and stays in L2).  16 MFMAs per chunk per
+// wave run on the operands of the previous fetch while the next chunk's 10 loads are in flight.
+typedef unsigned nhwc_u4 __attribute__((ext_vector_type(4)));
+
+struct NhwcChunk {
+    float a[2][4];   // [pixel tile][k-step]
+    float b[2][4];   // [channel tile][k-step]
+};
+
+__global__ void __launch_bounds__(256) conv2d_nhwc_tiled_kernel(const ConvNhwcArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int r = lane & 31, kq = lane >> 5;
+    const long long npix = (long long)a.n * a.ho * a.wo;
+    const long long pix0 = ((long long)blockIdx.x * 4 + wid) * 64;
+    const int co0 = blockIdx.y * 64;
+    if (pix0 >= npix)
+        return;
+    constexpr int OOB = 0x7ffffff0;
+    // whole tensors behind buffer descriptors: a lane with nothing to read uses an out-of-range offset and gets 0
+    const unsigned in_bytes = (unsigned)min((long long)a.n * a.h * a.w_ * a.cin * 4, (long long)0x7fffffff);
+    const unsigned w_bytes = (unsigned)((long long)a.kh * a.kw * a.cin * a.cout * 4);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, w_bytes, 0x00020000);
+    int oy[2], ox[2];
+    long long ibase[2];
+    bool pv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const long long pix = pix0 + t * 32 + r;
+        pv[t] = pix < npix;
+        const long long pc = pv[t] ? pix : 0;
+        ox[t] = (int)(pc % a.wo);
+        oy[t] = (int)((pc / a.wo) % a.ho);
+        ibase[t] = (pc / ((long long)a.wo * a.ho)) * a.h;
+    }
+    const bool cv[2] = {co0 + r < a.cout, co0 + 32 + r < a.cout};
+    const int nchunk = a.cin / 8;
+    const int total = a.kh * a.kw * nchunk;
+
+    auto fetch = [&](int it, NhwcChunk &q) {
+        const int tap = it / nchunk, c = (it - tap * nchunk) * 8;
+        const int ky = tap / a.kw, kx = tap - ky * a.kw;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int iy = oy[t] * a.stride - a.pad + ky, ix = ox[t] * a.stride - a.pad + kx;
+            const bool ok = pv[t] && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w_;
+            const long long off = (((ibase[t] + iy) * a.w_ + ix) * a.cin + c + 4 * kq) * 4;
+            const nhwc_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? (int)off : OOB, 0, 0);
+            const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];   // (bit_cast straight from v[i] reads element 0)
+            q.a[t][0] = __builtin_bit_cast(float, e0);
+            q.a[t][1] = __builtin_bit_cast(float, e1);
+            q.a[t][2] = __builtin_bit_cast(float, e2);
+            q.a[t][3] = __builtin_bit_cast(float, e3);
+        }
+        const int wrow = ((tap * a.cin + c + 4 * kq) * a.cout + co0 + r) * 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                q.b[u][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                          rw, cv[u] ? wrow + (s * a.cout + 32 * u) * 4 : OOB, 0, 0));
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            acc[t][u] = (f32x16)(0.0f);
+    NhwcChunk cur, nxt;
+    fetch(0, cur);
+    for (int it = 0; it < total; ++it) {
+        if (it + 1 < total)
+            fetch(it + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t][s], cur.b[u][s], acc[t][u], 0, 0, 0);
+        cur = nxt;
+    }
+    // D: column = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * kq (pixel)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int co = co0 + 32 * u + r;
+        if (co >= a.cout)
+            continue;
+        const float b = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const long long p = pix0 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kq;
+                if (p < npix) {
+                    float v = acc[t][u][reg] + b;
+                    if (a.relu)
+                        v = fmaxf(v, 0.0f);
+                    a.out[p * a.cout + co] = v;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // tf.image.crop_and_resize, method="bilinear", extrapolation_value=0.  One thread per
 // (box, y, x, channel); channels are innermost so loads/stores coalesce in NHWC.
 __global__ void __launch_bounds__(256)
@@ -408,6 +522,13 @@ gs_status gs_conv2d_nhwc(const float *in, int n, int h, int w, int cin, const fl
     a.wo = (w + 2 * pad - kw) / stride + 1;
     GS_REQUIRE(a.ho > 0 && a.wo > 0, "gs_conv2d_nhwc: empty output");
     const long long npix = (long long)n * a.ho * a.wo;
+    // tiled kernel: 8-channel chunks, 32-bit byte offsets into the input and the weights
+    if (cin % 8 == 0 && (long long)n * h * w * cin * 4 < 0x7fffffffLL && (long long)kh * kw * cin * cout * 4 < 0x7fffffffLL) {
+        dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((cout + 63) / 64));
+        hipLaunchKernelGGL(conv2d_nhwc_tiled_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
+        GS_HIP(hipGetLastError());
+        return GS_OK;
+    }
     dim3 grid((unsigned)((npix + 127) / 128), (unsigned)((cout + 31) / 32));
     hipLaunchKernelGGL(conv2d_nhwc_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
     GS_HIP(hipGetLastError());
@@ -442,8 +563,9 @@ gs_status gs_nms(const float *boxes, const float *scores, int k, float iou_thres
     GS_REQUIRE((size_t)words * 8 <= 64 * 1024, "gs_nms: more than %d boxes are not supported", 8192 * 64);
     // scratch: order[k] | n_valid | mask[k*words]
     const size_t scratch = round_up((size_t)(k + 4) * sizeof(int), 16) + (size_t)k * words * 8;
+    // stream-ordered scratch: no host synchronisation, the call stays asynchronous like the other primitives
     char *d = nullptr;
-    GS_HIP(hipMalloc(reinterpret_cast<void **>(&d), scratch));
+    GS_HIP(hipMallocAsync(reinterpret_cast<void **>(&d), scratch, s));
     int *order = reinterpret_cast<int *>(d);
     int *n_valid = order + k;
     unsigned long long *mask = reinterpret_cast<unsigned long long *>(d + round_up((size_t)(k + 4) * sizeof(int), 16));
@@ -454,8 +576,7 @@ gs_status gs_nms(const float *boxes, const float *scores, int k, float iou_thres
         hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)words * 8, s, mask, order, n_valid, words, max_out, keep, n_keep);
         e = hipGetLastError();
     }
-    hipError_t e2 = hipStreamSynchronize(s);   // scratch is freed below
-    hipFree(d);
+    hipError_t e2 = hipFreeAsync(d, s);
     GS_HIP(e);
     GS_HIP(e2);
     return GS_OK;

@@ -264,6 +264,20 @@ def test_detector_primitives_self_consistency(torch_mod):
                                   out.data_ptr(), None))
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max() <= 1e-4
+    # the tiled kernel (cin % 8 == 0): ragged pixel and channel tiles, stride 1 and 2, with and without bias / relu
+    for (cn, hh, ww, ci, co, st, relu, use_bias) in ((2, 21, 37, 16, 70, 1, 1, True), (3, 30, 19, 24, 64, 2, 0, False),
+                                                    (1, 9, 300, 8, 130, 1, 1, True)):
+        x = torch.randn(cn, hh, ww, ci, generator=g)
+        w = torch.randn(3, 3, ci, co, generator=g) * 0.1
+        bias = torch.randn(co, generator=g)
+        ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), bias if use_bias else None, st, 1)
+        ref = (torch.relu(ref) if relu else ref).permute(0, 2, 3, 1).contiguous()
+        xd, wd, bd = x.cuda(), w.cuda(), bias.cuda()
+        out = torch.full(ref.shape, float("nan"), device="cuda")
+        _lib.check(lib.gs_conv2d_nhwc(xd.data_ptr(), cn, hh, ww, ci, wd.data_ptr(), 3, 3, co, bd.data_ptr() if use_bias else None,
+                                      st, 1, relu, out.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert (out.cpu() - ref).abs().max() <= 2e-4, (cn, hh, ww, ci, co, st)
     # crop_and_resize
     feat = torch.randn(2, 11, 13, 5, generator=g)
     boxes = torch.tensor([[0.1, 0.2, 0.7, 0.9], [0.0, 0.0, 1.0, 1.0], [-0.2, 0.3, 0.5, 1.2]])
