@@ -476,12 +476,15 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
             const int cb = di == 0 ? 0 : NOUT1 + (di - 1) * NOUT;
             if (XMERGE) {
                 // per-wave LDS tile [MT rows][P*MT columns]; column i is input x' = x0 - 1 + i
-                float *tile = lds + a.lds_tile_off + wid * (MT * P * MT);
+                // row pitch P*MT + 4 floats: the four k-groups of a store write rows 4 apart, which a pitch of 128
+                // floats put on the same 16 banks (4-way conflict on every tile write)
+                constexpr int TS = P * MT + 4;
+                float *tile = lds + a.lds_tile_off + wid * (MT * TS);
 #pragma unroll
                 for (int r = 0; r < M::NACC; ++r)
 #pragma unroll
                     for (int p = 0; p < P; ++p)
-                        tile[M::row(r, kq) * (P * MT) + (VEC ? xl + p : p * MT + px)] = acc[p][r];
+                        tile[M::row(r, kq) * TS + (VEC ? xl + p : p * MT + px)] = acc[p][r];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -493,8 +496,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                     const int mc = mcol < XSTEP ? mcol : 0;
 #pragma unroll
                     for (int o = 0; o < NOUT1; ++o) {
-                        float v = tile[o * (P * MT) + mc] + tile[(NOUT1 + o) * (P * MT) + mc + 1] +
-                                  tile[(2 * NOUT1 + o) * (P * MT) + mc + 2];
+                        float v = tile[o * TS + mc] + tile[(NOUT1 + o) * TS + mc + 1] + tile[(2 * NOUT1 + o) * TS + mc + 2];
                         if (BNACT) {
                             v = v * bnp[o] + bnp[COUT + o];
                             v = fmaxf(v, 0.0f) + bnp[2 * COUT + o] * fminf(v, 0.0f);   // PReLU without a branch around the alpha read
@@ -587,7 +589,7 @@ gs_status launch_conv_mfma(ConvArgs a, int num_cus, hipStream_t stream)
         a.stagger = std::atoi(e);
     a.wfloats = conv_wfloats(CINP, TAPS, NDIL, NOUT1, NOUT, FLAGS & F_BNACT, FLAGS & F_DUAL, FLAGS & F_XMERGE);
     a.lds_tile_off = (a.wfloats + 255) / 256 * 256;
-    const size_t lds_bytes = (size_t)(a.lds_tile_off + ((FLAGS & F_XMERGE) ? WAVES * MT * P * MT : 0)) * sizeof(float);   // whole 1-KiB DMA pieces (+ tiles)
+    const size_t lds_bytes = (size_t)(a.lds_tile_off + ((FLAGS & F_XMERGE) ? WAVES * MT * (P * MT + 4) : 0)) * sizeof(float);   // whole 1-KiB DMA pieces (+ tiles)
     static bool attr_done = false;
     if (!attr_done) {
         GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

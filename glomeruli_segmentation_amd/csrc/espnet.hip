@@ -625,7 +625,15 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     }
     L.run(K_DEC_CONV, px1 * ((19 + CLS) * 9 * CLS * 2), [&] {
         if (m->variant != 30)
+        {
+            if (m->variant == 171)   // timing-only ablations
+                return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOEPI>(conv_args(m->a0, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
+            if (m->variant == 172)
+                return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOLOAD>(conv_args(m->a0, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
+            if (m->variant == 173)
+                return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOLOAD | F_X_NOEPI>(conv_args(m->a0, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
             return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE>(conv_args(m->a0, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
+        }
         return launch_conv_mfma<CFG_DEC_CONV, F_BNACT>(conv_args(m->a0, wb + m->wconv, m->ff, nullptr, n), m->num_cus, s);
     });
     set_stage("conv", m->ff, CLS);
