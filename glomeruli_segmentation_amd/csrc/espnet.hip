@@ -645,7 +645,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         a.mask = mask;
         a.hist = hist;
         a.N = n;
-        hipLaunchKernelGGL(dec4_kernel<CLS>, dim3(blocks_for((long long)H1 * W1), n), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(dec4_kernel<CLS>, dim3(blocks_for(((long long)H1 * W1 + DEC4_PX - 1) / DEC4_PX), n), dim3(256), 0, s, a);
         return GS_OK;
     });
     return L.st;

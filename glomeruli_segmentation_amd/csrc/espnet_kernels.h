@@ -390,6 +390,7 @@ struct Dec4Args {
     int N;
 };
 
+constexpr int DEC4_PX = 4;
 template <int CLS>
 __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
 {
@@ -397,20 +398,35 @@ __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
     const int H1 = a.f.H, W1 = a.f.W;
     const int H = 2 * H1, W = 2 * W1;
     const int n = blockIdx.y;   // one block never straddles two images
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (a.hist) {
-        if (threadIdx.x < CLS)
-            lhist[threadIdx.x] = 0;
-        __syncthreads();
-    }
-    int cls_of[4] = {-1, -1, -1, -1};   // class of this thread's four output pixels (-1: thread idle)
-    if (idx < H1 * W1) {
-        const int x = idx % W1;
-        const int y = idx / W1;
-        float s[CLS];
+    // classifier weights through LDS: read from global memory they were re-fetched with vector loads after every
+    // mask / logits store (possible aliasing), 395 loads per thread
+    __shared__ float wl[CLS * CLS * 4];
+    if (threadIdx.x < CLS * CLS * 4)
+        wl[threadIdx.x] = a.wcl[threadIdx.x];
+    if (threadIdx.x < CLS)
+        lhist[threadIdx.x] = 0;
+    __syncthreads();
+    // DEC4_PX half-scale pixels per thread, 256 apart, all their inputs requested before the first use: the kernel
+    // is a chain of dependent round trips (inputs -> arithmetic -> stores -> ballots -> atomics) and one pixel per
+    // thread left the memory system idle most of the time (0.085 ms for 0.1 GB)
+    int cls_of[DEC4_PX][4];
+    float s[DEC4_PX][CLS];
+    bool live[DEC4_PX];
+    int xs[DEC4_PX], ys[DEC4_PX];
+#pragma unroll
+    for (int q = 0; q < DEC4_PX; ++q) {
+        const int idx = (blockIdx.x * DEC4_PX + q) * 256 + threadIdx.x;
+        live[q] = idx < H1 * W1;
+        const int ic = live[q] ? idx : 0;
+        xs[q] = ic % W1;
+        ys[q] = ic / W1;
 #pragma unroll
         for (int k = 0; k < CLS; ++k)
-            s[k] = *at(a.f, n, k, y, x);
+            s[q][k] = *at(a.f, n, k, ys[q], xs[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < DEC4_PX; ++q) {
+        const int x = xs[q], y = ys[q];
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
             unsigned char m[2];
@@ -424,22 +440,22 @@ __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
                     float t = 0.0f;
 #pragma unroll
                     for (int i = 0; i < CLS; ++i)
-                        t = fmaf(s[i], a.wcl[((i * CLS + o) * 2 + dy) * 2 + dx], t);
+                        t = fmaf(s[q][i], wl[((i * CLS + o) * 2 + dy) * 2 + dx], t);
                     lg[o] = t;
                     if (o == 0 || t > best) {   // strict '>' : first maximum wins
                         best = t;
                         bi = o;
                     }
                 }
-                if (a.logits) {
+                if (a.logits && live[q]) {
 #pragma unroll
                     for (int o = 0; o < CLS; ++o)
                         a.logits[(((long long)n * CLS + o) * H + 2 * y + dy) * W + 2 * x + dx] = lg[o];
                 }
                 m[dx] = (unsigned char)bi;
-                cls_of[dy * 2 + dx] = bi;
+                cls_of[q][dy * 2 + dx] = live[q] ? bi : -1;   // -1: no pixel here
             }
-            if (a.mask)
+            if (a.mask && live[q])
                 *reinterpret_cast<uchar2 *>(a.mask + ((long long)n * H + 2 * y + dy) * W + 2 * x) = make_uchar2(m[0], m[1]);
         }
     }
@@ -450,8 +466,10 @@ __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
         for (int k = 0; k < CLS; ++k) {
             unsigned cnt = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                cnt += (unsigned)__popcll(__ballot(cls_of[j] == k));
+            for (int q = 0; q < DEC4_PX; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    cnt += (unsigned)__popcll(__ballot(cls_of[q][j] == k));
             if ((threadIdx.x & 63) == 0 && cnt)
                 atomicAdd(&lhist[k], cnt);
         }
