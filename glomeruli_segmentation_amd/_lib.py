@@ -5,6 +5,8 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libglomseg.so")
+# experiments only: an alternative build of the same library (e.g. other hipcc flags), never a different implementation
+LIB_PATH = os.environ.get("GLOMSEG_LIB", LIB_PATH)
 
 GS_OK = 0
 GS_IN_U8_BGR_NHWC = 0

@@ -89,11 +89,11 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 // N consecutive floats through one (N = 2, 4) or two (N = 8) buffer instructions.  Elements are copied out
 // before the bit cast: __builtin_bit_cast applied directly to v[j] reads element 0 with this hipcc.
-template <int N>
+template <int N, int AUX = 0>
 __device__ __forceinline__ void buf_load_vec(const __amdgpu_buffer_rsrc_t &rs, int voff, int soff, float *dst)
 {
     if constexpr (N == 2) {
-        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX);
         const unsigned e0 = v[0], e1 = v[1];
         dst[0] = __builtin_bit_cast(float, e0);
         dst[1] = __builtin_bit_cast(float, e1);
@@ -101,7 +101,7 @@ __device__ __forceinline__ void buf_load_vec(const __amdgpu_buffer_rsrc_t &rs, i
         static_assert(N == 4 || N == 8, "vector width");
 #pragma unroll
         for (int h = 0; h < N / 4; ++h) {
-            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * h, soff, 0);
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * h, soff, AUX);
             const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
             dst[4 * h + 0] = __builtin_bit_cast(float, e0);
             dst[4 * h + 1] = __builtin_bit_cast(float, e1);
@@ -114,14 +114,14 @@ __device__ __forceinline__ void buf_load_vec(const __amdgpu_buffer_rsrc_t &rs, i
 // constant 0: with an SGPR soffset hipcc assumes that a >64-bit buffer store has no write-data hazard and lets
 // the next VALU instruction overwrite the data registers, and on gfx950 the store then sometimes writes the new
 // register contents (seen as lane offsets appearing in the output).
-template <int N>
+template <int N, int AUX = 0>
 __device__ __forceinline__ void buf_store_vec(const __amdgpu_buffer_rsrc_t &rs, int voff, const float *src)
 {
     if constexpr (N == 2) {
         u32x2_t v;
         v[0] = __builtin_bit_cast(unsigned, src[0]);
         v[1] = __builtin_bit_cast(unsigned, src[1]);
-        __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff, 0, AUX);
     } else {
 #pragma unroll
         for (int h = 0; h < N / 4; ++h) {
@@ -129,7 +129,7 @@ __device__ __forceinline__ void buf_store_vec(const __amdgpu_buffer_rsrc_t &rs, 
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 v[j] = __builtin_bit_cast(unsigned, src[4 * h + j]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + 16 * h, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + 16 * h, 0, AUX);
         }
     }
 }
@@ -145,6 +145,13 @@ constexpr int F_S2PAIR = 512;   // STRIDE == 2, TAPS == 9: the three horizontal 
                                 // texture-address unit 16 cycles each (4 for a unit-stride one)
 constexpr int F_VEC = 1024;  // lane j owns P CONSECUTIVE pixels (instead of pixel j of P runs): operands, residual and
                              // results move as 8/16-byte accesses.  Needs STRIDE == 1, W % P == 0, P in {2, 4, 8}.
+// Cache policy of the once-only streams (aux bit 1 = nt, "non-temporal"): the residual is read once and the results are
+// read by a later kernel, so neither should displace the reduced map the taps re-read, and results written nt are not
+// left dirty in L2 for the kernel boundary to flush.  Measured per kernel (profiles/README.md); not used where it lost.
+constexpr int F_RES_NT = 8192;    // residual loads
+constexpr int F_ST_NT = 16384;    // result stores (first output)
+constexpr int F_ST2_NT = 32768;   // F_DUAL second output
+constexpr int F_IN_NT = 65536;    // activation (B operand) loads: inputs that are read once (1x1 reduces)
 constexpr int F_X_NOLOAD = 16;  // timing experiments only (results are garbage): no activation loads in the loop
 constexpr int F_X_NOLDS = 32;   // timing experiments only: no LDS weight reads in the loop
 constexpr int F_X_NOEPI = 64;   // timing experiments only: no epilogue at all
@@ -159,6 +166,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     constexpr bool BNACT = FLAGS & F_BNACT, RES = FLAGS & F_RES, STORE1 = !(FLAGS & F_NOSTORE), DUAL = FLAGS & F_DUAL;
     constexpr bool S2P = FLAGS & F_S2PAIR;
     constexpr bool VEC = FLAGS & F_VEC;
+    constexpr int IAUX = (FLAGS & F_IN_NT) ? 2 : 0;
+    constexpr int RAUX = (FLAGS & F_RES_NT) ? 2 : 0, SAUX = (FLAGS & F_ST_NT) ? 2 : 0, SAUX2 = (FLAGS & F_ST2_NT) ? 2 : 0;
     static_assert(!VEC || (STRIDE == 1 && (P == 2 || P == 4 || P == 8)), "F_VEC needs unit stride and P in {2,4,8}");
     static_assert(!S2P || (STRIDE == 2 && TAPS == 9 && NDIL == 1), "F_S2PAIR is for the stride-2 3x3 reduce");
     using M = Mfma<MT>;
@@ -291,13 +300,13 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                 const bool live = ch0 + kq * KSTR < nout;
                 const int sr = (cb + ch0) * a.res_sc * 4 + sres;
                 if (VEC) {
-                    buf_load_vec<P>(rres, live ? vr[0] : OOB, sr, resv[RES ? r : 0]);
+                    buf_load_vec<P, RAUX>(rres, live ? vr[0] : OOB, sr, resv[RES ? r : 0]);
                     continue;
                 }
 #pragma unroll
                 for (int p = 0; p < P; ++p)
                     resv[RES ? r : 0][p] = __builtin_bit_cast(
-                        float, __builtin_amdgcn_raw_buffer_load_b32(rres, live ? vr[p] : OOB, sr, 0));
+                        float, __builtin_amdgcn_raw_buffer_load_b32(rres, live ? vr[p] : OOB, sr, RAUX));
             }
         };
 
@@ -323,13 +332,13 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                 return;
             }
             if (VEC) {
-                buf_load_vec<P>(rs, voff, soff, bq[S2P ? 0 : g * TXN + tx]);
+                buf_load_vec<P, IAUX>(rs, voff, soff, bq[S2P ? 0 : g * TXN + tx]);
                 return;
             }
 #pragma unroll
             for (int p = 0; p < P; ++p)
                 bq[g * TXN + tx][p] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + p * MT * STRIDE * 4, soff, 0));
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + p * MT * STRIDE * 4, soff, IAUX));
         };
         auto fetch_pair = [&](const __amdgpu_buffer_rsrc_t &rs, int sb, int c, int g) {
             const int rg = c * G + g;
@@ -338,7 +347,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
             const int soff = sb + ((ty - 1) * a.in_pitch - 1 + sidx * KL * a.in_sc) * 4;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff + p * MT * STRIDE * 4, soff, 0);
+                const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff + p * MT * STRIDE * 4, soff, IAUX);
                 // (copy the elements out first: __builtin_bit_cast applied directly to v[1] reads element 0 with this hipcc)
                 const unsigned e0 = v[0], e1 = v[1], e2 = v[2];
                 bl[g][p][0] = __builtin_bit_cast(float, e0);
@@ -542,20 +551,20 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                     }
                     o1[p] = v;
                     if (!VEC && STORE1)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, live ? vo[p] : OOB, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, live ? vo[p] : OOB, so, SAUX);
                     if (DUAL) {
                         float v2 = v * scale2 + shift2;
                         v2 = v2 > 0.0f ? v2 : alpha2 * v2;
                         o2[p] = v2;
                         if (!VEC)
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2), rout2,
-                                                                  live ? vo2[p] : OOB, so2, 0);
+                                                                  live ? vo2[p] : OOB, so2, SAUX2);
                     }
                 }
                 if (VEC && STORE1)
-                    buf_store_vec<P>(rout, live ? vo[0] + so : OOB, o1);
+                    buf_store_vec<P, SAUX>(rout, live ? vo[0] + so : OOB, o1);
                 if (VEC && DUAL)
-                    buf_store_vec<P>(rout2, live ? vo2[0] + so2 : OOB, o2);
+                    buf_store_vec<P, SAUX2>(rout2, live ? vo2[0] + so2 : OOB, o2);
             }
             if (di + 1 < NDIL)
                 prefetch_res(di + 1);

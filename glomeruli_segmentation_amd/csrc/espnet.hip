@@ -58,6 +58,38 @@ static gs_status launch_vec(const ConvArgs &ca, int num_cus, hipStream_t s)
         return launch_conv_mfma<C..., FLAGS | F_VEC>(ca, num_cus, s);
     return launch_conv_mfma<C..., FLAGS>(ca, num_cus, s);
 }
+// cache-policy flags per launch class (F_RES_NT / F_ST_NT / F_ST2_NT, conv_mfma.h)
+#ifndef POL_L2_DOWN
+#define POL_L2_DOWN (F_ST_NT | F_ST2_NT)
+#endif
+#ifndef POL_L2_ESP
+#define POL_L2_ESP (F_RES_NT | F_ST_NT)
+#endif
+#ifndef POL_L2_LAST
+#define POL_L2_LAST (F_RES_NT | F_ST2_NT)
+#endif
+#ifndef POL_L3_DOWN
+#define POL_L3_DOWN 0
+#endif
+#ifndef POL_L3_ESP
+#define POL_L3_ESP F_RES_NT
+#endif
+#ifndef POL_L2_C1
+#define POL_L2_C1 0
+#endif
+#ifndef POL_L3_C1
+#define POL_L3_C1 0
+#endif
+#ifndef POL_L2_C1S
+#define POL_L2_C1S 0
+#endif
+#ifndef POL_L3_C1S
+#define POL_L3_C1S F_IN_NT   // 0.179 -> 0.165 ms; the same flag on the other inputs lost (decoder conv 0.19 -> 0.41: it lives on L2 row reuse)
+#endif
+#ifndef POL_DEC_CONV
+#define POL_DEC_CONV 0
+#endif
+
 enum KernelId {
     K_STEM, K_POOL, K_L2_C1S, K_L2_DOWN, K_L2_C1, K_L2_ESP, K_CAT_B2, K_L3_C1S, K_L3_DOWN, K_L3_C1, K_L3_ESP,
     K_DEC1, K_DEC2, K_DEC3, K_DEC_CONV, K_DEC4, K_COUNT
@@ -416,7 +448,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     L.run(K_L2_C1S, px2 * (19 * 9 * 12 * 2), [&] {
         if (m->variant == 41)
             return launch_conv_mfma<CFG_L2_C1S, 0>(conv_args(m->a0, wb + m->l2_0.c1, m->r2, nullptr, n), m->num_cus, s);
-        return launch_conv_mfma<CFG_L2_C1S, F_S2PAIR>(conv_args(m->a0, wb + m->l2_0.c1, m->r2, nullptr, n), m->num_cus, s);
+        return launch_conv_mfma<CFG_L2_C1S, F_S2PAIR | POL_L2_C1S>(conv_args(m->a0, wb + m->l2_0.c1, m->r2, nullptr, n), m->num_cus, s);
     });
     // b2 = BR(131) over cat([output1, output1_0, inp2]) (Model.py:359) is fused into its producers:
     // the down-sampler stores output1_0 twice (raw for the ESP blocks, b2-normalised into planes
@@ -438,9 +470,9 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         if (fuse_b2) {
             ca = with_dual(ca, 64);
             if (m->variant == 150) return launch_vec<F_BNACT | F_DUAL, CFG_L2_BR>(ca, m->num_cus, s);
-            return launch_vec<F_BNACT | F_DUAL, CFG_L2_BR_P4>(ca, m->num_cus, s);
+            return launch_vec<F_BNACT | F_DUAL | POL_L2_DOWN, CFG_L2_BR_P4>(ca, m->num_cus, s);
         }
-        return launch_vec<F_BNACT, CFG_L2_BR_P4>(ca, m->num_cus, s);
+        return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT), CFG_L2_BR_P4>(ca, m->num_cus, s);
     });
     set_stage("level2_0", m->bb[0], 64);
     int cur2 = 0;
@@ -449,7 +481,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         const bool last = i == m->p - 1;
         L.run(K_L2_C1, px2 * (64 * 12 * 2), [&] {
             ConvArgs ca = conv_args(m->bb[cur2], wb + m->l2[i].c1, m->r2, nullptr, n);
-            return launch_conv_mfma<CFG_L2_C1, 0>(ca, m->num_cus, s);   // 1x1: the run mapping measured no slower
+            return launch_conv_mfma<CFG_L2_C1, POL_L2_C1>(ca, m->num_cus, s);   // 1x1: the run mapping measured no slower
         });
         L.run(K_L2_ESP, px2 * (12 * 9 * 64 * 2), [&] {
             ConvArgs ca = conv_args(m->r2, wb + m->l2[i].br, m->bb[nxt], &m->bb[cur2], n);
@@ -481,10 +513,10 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             if (last) {
                 ca = with_dual(ca, 0);
                 if (m->variant == 150) return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL, CFG_L2_BR>(ca, m->num_cus, s);
-                return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL, CFG_L2_BR_P4>(ca, m->num_cus, s);
+                return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST, CFG_L2_BR_P4>(ca, m->num_cus, s);
             }
             if (m->variant == 150) return launch_vec<F_BNACT | F_RES, CFG_L2_BR>(ca, m->num_cus, s);
-            return launch_vec<F_BNACT | F_RES, CFG_L2_BR_P4>(ca, m->num_cus, s);
+            return launch_vec<F_BNACT | F_RES | POL_L2_ESP, CFG_L2_BR_P4>(ca, m->num_cus, s);
         });
         cur2 = nxt;
         if (!last)
@@ -503,11 +535,11 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     L.run(K_L3_C1S, px3 * (131 * 9 * 25 * 2), [&] {
         if (m->variant == 41)
             return launch_conv_mfma<CFG_L3_C1S, 0>(conv_args(m->a1, wb + m->l3_0.c1, m->r3, nullptr, n), m->num_cus, s);
-        return launch_conv_mfma<CFG_L3_C1S, F_S2PAIR>(conv_args(m->a1, wb + m->l3_0.c1, m->r3, nullptr, n), m->num_cus, s);
+        return launch_conv_mfma<CFG_L3_C1S, F_S2PAIR | POL_L3_C1S>(conv_args(m->a1, wb + m->l3_0.c1, m->r3, nullptr, n), m->num_cus, s);
     });
     L.run(K_L3_DOWN, px3 * (25 * 9 * 128 * 2), [&] {
         ConvArgs ca = conv_args(m->r3, wb + m->l3_0.br, m->cc[0], nullptr, n);
-        return launch_vec<F_BNACT, CFG_L3_BR>(ca, m->num_cus, s);
+        return launch_vec<F_BNACT | POL_L3_DOWN, CFG_L3_BR>(ca, m->num_cus, s);
     });
     set_stage("level3_0", m->cc[0], 128);
     int cur3 = 0;
@@ -515,7 +547,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         const int nxt = cur3 == 1 ? 2 : 1;
         L.run(K_L3_C1, px3 * (128 * 25 * 2), [&] {
             ConvArgs ca = conv_args(m->cc[cur3], wb + m->l3[i].c1, m->r3, nullptr, n);
-            return launch_conv_mfma<CFG_L3_C1, 0>(ca, m->num_cus, s);
+            return launch_conv_mfma<CFG_L3_C1, POL_L3_C1>(ca, m->num_cus, s);
         });
         L.run(K_L3_ESP, px3 * (25 * 9 * 128 * 2), [&] {
             ConvArgs ca = conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n);
@@ -525,7 +557,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
                 // four consecutive pixels per lane and 16-byte accesses when the width allows it (0.170 ms per
                 // launch at batch 32), else the two-run mapping with its deeper ring (0.175 ms)
                 if (ca.W % 4 == 0 && !getenv_flag("GS_NO_VEC"))
-                    return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC>(ca, m->num_cus, s);
+                    return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | POL_L3_ESP>(ca, m->num_cus, s);
                 return launch_conv_mfma<CFG_L3_BR_P2, F_BNACT | F_RES>(ca, m->num_cus, s);
             }
             if (m->variant >= 2 && m->variant < 100)
@@ -632,7 +664,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
                 return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOLOAD>(conv_args(m->a0, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
             if (m->variant == 173)
                 return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOLOAD | F_X_NOEPI>(conv_args(m->a0, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
-            return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE>(conv_args(m->a0, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
+            return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | POL_DEC_CONV>(conv_args(m->a0, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
         }
         return launch_conv_mfma<CFG_DEC_CONV, F_BNACT>(conv_args(m->a0, wb + m->wconv, m->ff, nullptr, n), m->num_cus, s);
     });
