@@ -134,6 +134,19 @@ __device__ __forceinline__ void buf_store_vec(const __amdgpu_buffer_rsrc_t &rs, 
     }
 }
 
+// PReLU in two VALU instructions: for slope a <= 1 (negative slopes included) PReLU(v) = max(v, a*v), for a > 1 it is
+// min(v, a*v); both are the median of (v, a*v, pin) with pin = +inf resp. -inf, a per-channel constant.  Bit-identical
+// to the select form (the same a*v, the same v).  Next to fp32 MFMAs every VALU instruction of the epilogue costs
+// the issuing wave about one MFMA slot, so the compare / select pair it replaces was worth removing.
+__device__ __forceinline__ float prelu_pin(float alpha)
+{
+    return alpha <= 1.0f ? __builtin_inff() : -__builtin_inff();
+}
+__device__ __forceinline__ float prelu_med3(float v, float alpha, float pin)
+{
+    return __builtin_amdgcn_fmed3f(v, alpha * v, pin);
+}
+
 // epilogue flags
 constexpr int F_BNACT = 1;   // folded BatchNorm + PReLU on the way out
 constexpr int F_RES = 2;     // add the residual input before BN (ESP block, Model.py:211-213)
@@ -508,7 +521,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                         float v = tile[o * TS + mc] + tile[(NOUT1 + o) * TS + mc + 1] + tile[(2 * NOUT1 + o) * TS + mc + 2];
                         if (BNACT) {
                             v = v * bnp[o] + bnp[COUT + o];
-                            v = fmaxf(v, 0.0f) + bnp[2 * COUT + o] * fminf(v, 0.0f);   // PReLU without a branch around the alpha read
+                            const float al = bnp[2 * COUT + o];
+                            v = prelu_med3(v, al, prelu_pin(al));
                         }
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, ok ? mcol * 4 : OOB,
                                                               o * a.out_sc * 4 + sout, 0);
@@ -540,6 +554,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                     }
                 }
                 float o1[P], o2[P];
+                const float pin = prelu_pin(alpha), pin2 = prelu_pin(alpha2);
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     float v = acc[p][r];
@@ -547,14 +562,14 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                         v += resv[RES ? r : 0][p];
                     if (BNACT) {
                         v = v * scale + shift;
-                        v = v > 0.0f ? v : alpha * v;
+                        v = prelu_med3(v, alpha, pin);
                     }
                     o1[p] = v;
                     if (!VEC && STORE1)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, live ? vo[p] : OOB, so, SAUX);
                     if (DUAL) {
                         float v2 = v * scale2 + shift2;
-                        v2 = v2 > 0.0f ? v2 : alpha2 * v2;
+                        v2 = prelu_med3(v2, alpha2, pin2);
                         o2[p] = v2;
                         if (!VEC)
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2), rout2,

@@ -61,7 +61,8 @@ __device__ __forceinline__ void st_stream(T *p, T v)
 // for it inside the branch: one serialised round trip per activation.
 __device__ __forceinline__ float prelu(float v, float alpha)
 {
-    return fmaxf(v, 0.0f) + alpha * fminf(v, 0.0f);
+    // median form (conv_mfma.h, prelu_med3): alpha is uniform here, so the +-inf pin is a scalar select
+    return __builtin_amdgcn_fmed3f(v, alpha * v, alpha <= 1.0f ? __builtin_inff() : -__builtin_inff());
 }
 __device__ __forceinline__ float bn_prelu(float v, const float *bnp, int C, int c)
 {
