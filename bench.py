@@ -188,18 +188,21 @@ def main():
         for k in prof:
             kernels[k["name"]] = {"avg_ms": round(k["total_ms"] / max(k["launches"], 1), 4), "launches": k["launches"]}
         traffic = None
+        traffic_detail = None
         tpath = os.path.join(REPO, "profiles", "r01_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             if tj.get("kernel") == DOMINANT:
-                traffic = {"bytes_per_launch": tj["traffic_bytes_per_launch"],
-                           "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"], "source": tj["source"]}
+                traffic = tj["traffic_bytes_per_launch"]          # HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)
+                traffic_detail = {"algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"], "source": tj["source"],
+                                  "correction": tj.get("correction")}
         if dom:
             avg_s = dom["total_ms"] / dom["launches"] * 1e-3
             achieved = dom["flops_per_tile"] * BATCH / avg_s / 1e12
             roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_detail": traffic_detail,
                     "avg_launch_ms": round(avg_s * 1e3, 4),
                     "launches_timed": dom["launches"], "instrumented_ms_per_step": round(elapsed_prof / args.steps * 1e3, 3),
                     "whole_net_frac": round(value / n * FLOP_PER_TILE / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
