@@ -37,7 +37,6 @@ void set_error(const char *fmt, ...)
 #define CFG_L3_C1S       32, 8,   132, 9,   2,     1,   25,   25,   4, 6
 #define CFG_L3_C1        32, 8,   128, 1,   1,     1,   25,   25,   4, 16
 #define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 3
-#define CFG_L3_BR_W16    32, 16,  26,  9,   1,     5,   28,   25,   2, 3
 #define CFG_L3_BR_P2     32, 8,   26,  9,   1,     5,   28,   25,   2, 13
 #define CFG_DEC_CONV     16, 8,   24,  9,   1,     1,   5,    5,    8, 3
 #define CFG_DEC_CONV_XM  16, 8,   24,  3,   1,     1,   5,    5,    8, 6
@@ -551,8 +550,6 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         });
         L.run(K_L3_ESP, px3 * (25 * 9 * 128 * 2), [&] {
             ConvArgs ca = conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n);
-            if (m->variant == 1)
-                return launch_conv_mfma<CFG_L3_BR_W16, F_BNACT | F_RES | F_VEC>(ca, m->num_cus, s);
             if (m->variant == 0 || m->variant == 30) {
                 // four consecutive pixels per lane and 16-byte accesses when the width allows it (0.170 ms per
                 // launch at batch 32), else the two-run mapping with its deeper ring (0.175 ms)
@@ -560,17 +557,25 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
                     return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | POL_L3_ESP>(ca, m->num_cus, s);
                 return launch_conv_mfma<CFG_L3_BR_P2, F_BNACT | F_RES>(ca, m->num_cus, s);
             }
-            if (m->variant >= 2 && m->variant < 100)
-                ca.stagger = m->variant - 1;
-            if (m->variant == 105) {
+            // Diagnostic builds of this kernel (GS_VARIANT; results are wrong by construction except 105):
+            //   101 no epilogue   102 no epilogue, no operand loads   103 ... and no LDS reads   104 no operand loads
+            //   105 per-wave stamps -> gpurun_out/stamps.txt (tools/stamps.py)   109 stores but no residual
+            switch (m->variant) {
+            case 101: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | F_X_NOEPI>(ca, m->num_cus, s);
+            case 102: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI | F_X_NOLOAD>(ca, m->num_cus, s);
+            case 103: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI | F_X_NOLOAD | F_X_NOLDS>(ca, m->num_cus, s);
+            case 104: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_X_NOLOAD>(ca, m->num_cus, s);
+            case 109: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_VEC>(ca, m->num_cus, s);
+            case 105: {
                 static unsigned long long *stamp = nullptr;
-                if (!stamp) hipMalloc(reinterpret_cast<void **>(&stamp), 4096 * 8 * 8);
-                hipMemsetAsync(stamp, 0, 4096 * 8 * 8, s);
+                if (!stamp)
+                    GS_HIP(hipMalloc(reinterpret_cast<void **>(&stamp), 4096 * 8 * 8));
+                GS_HIP(hipMemsetAsync(stamp, 0, 4096 * 8 * 8, s));
                 ca.stamp = stamp;
                 gs_status st = launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_X_STAMP>(ca, m->num_cus, s);
                 if (i == m->q - 1) {
                     std::vector<unsigned long long> h(2048 * 8);
-                    hipMemcpy(h.data(), stamp, h.size() * 8, hipMemcpyDeviceToHost);
+                    GS_HIP(hipMemcpy(h.data(), stamp, h.size() * 8, hipMemcpyDeviceToHost));
                     if (FILE *f = std::fopen("gpurun_out/stamps.txt", "w")) {
                         for (int w = 0; w < 2048; ++w) {
                             for (int k = 0; k < 7; ++k) std::fprintf(f, "%llu ", h[w * 8 + k]);
@@ -581,23 +586,8 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
                 }
                 return st;
             }
-            if (m->variant == 106)   // residual loads but no stores (timing only)
-                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_NOSTORE>(ca, m->num_cus, s);
-            if (m->variant == 107)   // stores but no residual (timing only)
-                return launch_conv_mfma<CFG_L3_BR, F_BNACT>(ca, m->num_cus, s);
-            if (m->variant == 101)
-                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI>(ca, m->num_cus, s);
-            if (m->variant == 108)
-                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | F_X_NOEPI>(ca, m->num_cus, s);
-            if (m->variant == 109)   // stores, no residual
-                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_VEC>(ca, m->num_cus, s);
-            if (m->variant == 102)
-                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI | F_X_NOLOAD>(ca, m->num_cus, s);
-            if (m->variant == 103)
-                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI | F_X_NOLOAD | F_X_NOLDS>(ca, m->num_cus, s);
-            if (m->variant == 104)
-                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_X_NOLOAD>(ca, m->num_cus, s);
-            return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES>(ca, m->num_cus, s);
+            default: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES>(ca, m->num_cus, s);
+            }
         });
         cur3 = nxt;
         set_stage("level3." + std::to_string(i), m->cc[cur3], 128);
