@@ -430,9 +430,9 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         a.H = H;
         a.W = W;
         if (in_format == GS_IN_U8_BGR_NHWC)
-            hipLaunchKernelGGL(stem_kernel<true>, dim3(blocks_for((long long)n * H1 * W1)), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(stem_kernel<true>, dim3(blocks_for((long long)n * H1 * ((W1 + STEM_PX - 1) / STEM_PX))), dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL(stem_kernel<false>, dim3(blocks_for((long long)n * H1 * W1)), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(stem_kernel<false>, dim3(blocks_for((long long)n * H1 * ((W1 + STEM_PX - 1) / STEM_PX))), dim3(256), 0, s, a);
         return GS_OK;
     });
     L.run(K_POOL, 0, [&] {

@@ -42,6 +42,7 @@ __device__ __forceinline__ float ldz(const ActV &t, int n, int c, int y, int x)
 #ifndef NT_DEC4_ST
 #define NT_DEC4_ST 1
 #endif
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 template <bool NT>
 __device__ __forceinline__ float ld_stream(const float *p)
 {
@@ -109,6 +110,9 @@ __device__ __forceinline__ float stem_fetch(const StemArgs &a, const float (*lut
     return ok ? v : 0.0f;
 }
 
+// Two horizontally adjacent output pixels per thread: the 3x5 input window is fetched once (15 values per channel
+// instead of 18), every weight that arrives in an SGPR feeds two FMAs, and the 19 + 3 results leave as 8-byte stores.
+constexpr int STEM_PX = 2;
 template <bool U8>
 __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
 {
@@ -124,56 +128,77 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
         __syncthreads();
     }
     const int H1 = a.H / 2, W1 = a.W / 2;
+    const int W1p = (W1 + STEM_PX - 1) / STEM_PX;   // pixel pairs per row
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)a.N * H1 * W1)
+    if (idx >= (long long)a.N * H1 * W1p)
         return;
-    const int x = (int)(idx % W1);
-    const int y = (int)((idx / W1) % H1);
-    const int n = (int)(idx / ((long long)W1 * H1));
+    const int x = (int)(idx % W1p) * STEM_PX;
+    const int y = (int)((idx / W1p) % H1);
+    const int n = (int)(idx / ((long long)W1p * H1));
+    const bool two = x + 1 < W1;
 
-    float v[3][3][3];
+    float v[3][3][2 * STEM_PX + 1];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
+            for (int kx = 0; kx < 2 * STEM_PX + 1; ++kx)
                 v[c][ky][kx] = stem_fetch<U8>(a, lut, n, c, 2 * y - 1 + ky, 2 * x - 1 + kx);
 
     // all arithmetic first, all stores last: a store between two weight reads would force hipcc to
     // re-read the (possibly aliasing) weights from memory with vector loads and a full wait each time
-    float outv[19], poolv[3];
+    float outv[19][STEM_PX], poolv[3][STEM_PX];
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
-        float s = 0.0f;
+        float s[STEM_PX];
+#pragma unroll
+        for (int q = 0; q < STEM_PX; ++q)
+            s[q] = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float wgt = a.w1[((o * 3 + c) * 3 + ky) * 3 + kx];
+#pragma unroll
+                    for (int q = 0; q < STEM_PX; ++q)
+                        s[q] = fmaf(wgt, v[c][ky][2 * q + kx], s[q]);
+                }
+#pragma unroll
+        for (int q = 0; q < STEM_PX; ++q)
+            outv[o][q] = bn_prelu_sel(bn_prelu_sel(s[q], a.bn1, 16, o), a.b1, 19, o);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < STEM_PX; ++q) {
+            float s = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
-                    s = fmaf(a.w1[((o * 3 + c) * 3 + ky) * 3 + kx], v[c][ky][kx], s);
-        s = bn_prelu_sel(s, a.bn1, 16, o);
-        outv[o] = bn_prelu_sel(s, a.b1, 19, o);
+                    s += v[c][ky][2 * q + kx];
+            s = s / 9.0f;   // count_include_pad=True
+            poolv[c][q] = s;
+            outv[16 + c][q] = bn_prelu_sel(s, a.b1, 19, 16 + c);
+        }
+    // interior rows start on a 128-byte line and x is even: the pair is one aligned 8-byte store
+#pragma unroll
+    for (int o = 0; o < 19; ++o) {
+        if (two)
+            st_stream<NT_STEM_ST>(reinterpret_cast<f32x2_t *>(at(a.a0, n, o, y, x)), f32x2_t{outv[o][0], outv[o][1]});
+        else
+            st_stream<NT_STEM_ST>(at(a.a0, n, o, y, x), outv[o][0]);
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float s = 0.0f;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-                s += v[c][ky][kx];
-        s = s / 9.0f;   // count_include_pad=True
-        poolv[c] = s;
-        outv[16 + c] = bn_prelu_sel(s, a.b1, 19, 16 + c);
+        if (two)
+            st_stream<NT_STEM_ST>(reinterpret_cast<f32x2_t *>(at(a.inp1, n, c, y, x)), f32x2_t{poolv[c][0], poolv[c][1]});
+        else
+            st_stream<NT_STEM_ST>(at(a.inp1, n, c, y, x), poolv[c][0]);
     }
-#pragma unroll
-    for (int o = 0; o < 19; ++o)
-        st_stream<NT_STEM_ST>(at(a.a0, n, o, y, x), outv[o]);
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-        st_stream<NT_STEM_ST>(at(a.inp1, n, c, y, x), poolv[c]);
 }
 
 // second AvgPool2d(3,2,1) of sample2.  reference: Model.py:232-239,348
