@@ -572,7 +572,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
                     GS_HIP(hipMalloc(reinterpret_cast<void **>(&stamp), 4096 * 8 * 8));
                 GS_HIP(hipMemsetAsync(stamp, 0, 4096 * 8 * 8, s));
                 ca.stamp = stamp;
-                gs_status st = launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_X_STAMP>(ca, m->num_cus, s);
+                gs_status st = launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | POL_L3_ESP | F_X_STAMP>(ca, m->num_cus, s);
                 if (i == m->q - 1) {
                     std::vector<unsigned long long> h(2048 * 8);
                     GS_HIP(hipMemcpy(h.data(), stamp, h.size() * 8, hipMemcpyDeviceToHost));
