@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                             v = prelu_med3(v, al, prelu_pin(al));
                         }
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, ok ? mcol * 4 : OOB,
-                                                              o * a.out_sc * 4 + sout, 0);
+                                                              o * a.out_sc * 4 + sout, SAUX);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();   // the tile is rewritten by this wave's next task
