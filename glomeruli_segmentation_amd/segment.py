@@ -74,11 +74,14 @@ def metric_right(hist):
 def segment_images(engine, images, mean, std, width, height, batch):
     """images: list of HxWx3 uint8 BGR crops of any size -> list of class maps at crop size.
     Crops already at network size go down the fused uint8 path (normalisation in the first kernel);
-    others are normalised + resized on the host exactly in the reference's order (:107-116)."""
+    others are normalised + resized on the GPU exactly in the reference's order (:107-116).
+    With an encoder-only engine (modelType 2) every crop takes the second route and the 1/8-scale
+    logits are upsampled x8 bilinearly as the reference's `up` module does (:259-261,125-126)."""
     import torch
     out = [None] * len(images)
-    native = [i for i, im in enumerate(images) if im.shape[:2] == (height, width)]
-    other = [i for i in range(len(images)) if images[i].shape[:2] != (height, width)]
+    enc = engine.encoder_only
+    native = [] if enc else [i for i, im in enumerate(images) if im.shape[:2] == (height, width)]
+    other = [i for i in range(len(images)) if enc or images[i].shape[:2] != (height, width)]
     for s in range(0, len(native), batch):
         idx = native[s:s + batch]
         tiles = torch.from_numpy(np.stack([images[i] for i in idx])).to(engine.device)
@@ -92,7 +95,10 @@ def segment_images(engine, images, mean, std, width, height, batch):
         x = torch.empty((len(idx), 3, height, width), dtype=torch.float32, device=engine.device)
         for j, i in enumerate(idx):      # crop stage on the GPU: normalise + bilinear resize fused (:107-116)
             crop_preprocess(torch.from_numpy(images[i]).to(engine.device), mean, std, height, width, out=x[j])
-        cls = engine.forward_logits(x).max(1)[1].byte()       # :128
+        logits = engine.forward_logits(x)
+        if enc:
+            logits = torch.nn.functional.interpolate(logits, scale_factor=8, mode="bilinear", align_corners=False)
+        cls = logits.max(1)[1].byte()       # :128
         for j, i in enumerate(idx):
             h, w = images[i].shape[:2]
             out[i] = mask_resize_nearest(cls[j], h, w).cpu().numpy()    # :129
@@ -201,9 +207,12 @@ def main(argv=None):
     print("num of image:{}".format(len(rgb_list)))
     sd = load_state_dict_file(args.weights)
     if args.modelType == 2:
-        raise SystemExit("modelType 2 (ESPNet-C + bilinear x8 upsampling) is served by Model.ESPNet_Encoder; "
-                         "the batch driver covers modelType 1")
-    engine = EspnetEngine(sd, classes=args.classes, p=args.p, q=args.q)
+        # ESPNet-C (:267-272): the checkpoint holds the encoder's own keys; a full-network checkpoint is accepted too
+        if any(k.startswith("encoder.") for k in sd):
+            sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+        engine = EspnetEngine(sd, classes=args.classes, p=args.p, q=args.q, encoder_only=True)
+    else:
+        engine = EspnetEngine(sd, classes=args.classes, p=args.p, q=args.q)
     evaluate(args, engine, rgb_list, label_list)
     engine.close()
     return 0

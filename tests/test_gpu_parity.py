@@ -245,6 +245,32 @@ def test_driver_end_to_end(torch_mod, tmp_path):
     assert (out / "PAS-001" / "xmin0_ymin0_xmax128_ymax64_overlay.jpg").exists()
 
 
+def test_driver_model_type_2(torch_mod, tmp_path):
+    """--modelType 2: ESPNet-C logits at 1/8 scale + the reference's bilinear x8 upsampling, against the golden
+    encoder output pushed through the same torch upsampling"""
+    from PIL import Image
+    from conftest import GOLDEN
+    from glomeruli_segmentation_amd import segment
+    torch = torch_mod
+    z = load_golden("encoder_fold1.npz")
+    tile = z["tile"]
+    h, w = tile.shape[:2]
+    d = tmp_path / "org_image" / "PAS-002"
+    d.mkdir(parents=True)
+    Image.fromarray(tile[:, :, ::-1]).save(d / "xmin0_ymin0_xmax1_ymax1.PNG")
+    out = tmp_path / "results"
+    rc = segment.main(["--rgb_data_dir", str(tmp_path / "org_image"), "--savedir", str(out), "--weights",
+                       os.path.join(GOLDEN, "weights_fold1.npz"), "--gpu_id", "0", "--modelType", "2", "--inWidth", str(w),
+                       "--inHeight", str(h), "--mean", "204.60071", "170.19359", "199.57469", "--std", "20.61257", "42.92207",
+                       "28.401505"])
+    assert rc == 0
+    exp = torch.nn.functional.interpolate(torch.from_numpy(z["out"])[None], scale_factor=8, mode="bilinear",
+                                          align_corners=False)[0].max(0)[1].numpy()
+    cm = np.asarray(Image.open(out / "PAS-002" / "xmin0_ymin0_xmax1_ymax1_classmap.png"))
+    assert cm.shape == exp.shape
+    assert (cm != exp).mean() <= 1e-3
+
+
 def test_detector_primitives_self_consistency(torch_mod):
     """conv2d NHWC / crop_and_resize / NMS against torch CPU ops and a numpy restatement of the
     published TF semantics.  NOT reference parity (the detector graph is external)."""
