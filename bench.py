@@ -189,8 +189,10 @@ def main():
             kernels[k["name"]] = {"avg_ms": round(k["total_ms"] / max(k["launches"], 1), 4), "launches": k["launches"]}
         traffic = None
         traffic_detail = None
-        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if os.path.exists(tpath):
+        import glob
+        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")))   # newest round's rocprofv3 --pmc passes
+        tpath = cands[-1] if cands else ""
+        if tpath and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             if tj.get("kernel") == DOMINANT:
