@@ -21,9 +21,20 @@
 //   * the lane<->pixel, register<->channel accumulator layout stores 128-byte (MT=32) or 64-byte
 //     (MT=16) row segments per channel plane.
 #pragma once
+#include <map>
+#include <mutex>
+
 #include "gs_internal.h"
 
 namespace gs {
+
+// Timing / ablation variants (results wrong by construction), per-wave stamps and the launch-time environment knobs
+// exist only in builds made with -DGS_DIAG; the product library contains none of them and reads no environment.
+#ifdef GS_DIAG
+constexpr bool kDiag = true;
+#else
+constexpr bool kDiag = false;
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -74,10 +85,16 @@ struct ConvArgs {
     long long out2_sn;
     int out2_sc, out2_pitch, out2_off, out2_coff;
     unsigned out2_img_bytes;
+    // F_FUSE1X1: the NEXT block's 1x1 reduce (Model.py:193 `output1 = self.c1(input)`) of this kernel's output
+    float *out3;
+    long long out3_sn;
+    int out3_sc, out3_pitch, out3_off, nout3;
+    unsigned out3_img_bytes;
     int lds_tile_off;   // F_XMERGE: float offset of the per-wave LDS tiles (after the weight image)
+    // GS_DIAG builds only:
     int stagger;   // units of 1024 cycles by which waves WAVES/2.. start late (0 = off)
-    int prio_mode; // wave priority of the two halves of a workgroup: 0 alternates per dilation, 1 per task, 2 off, 3 fixed
-    unsigned long long *stamp;   // F_X_STAMP diagnostic builds only: [wave][8] 100 MHz timestamps
+    int prio_mode; // wave priority of the two halves of a workgroup: 0 alternates per dilation, 1 per task (shipped), 2 off, 3 fixed
+    unsigned long long *stamp;   // F_X_STAMP: [wave][8] 100 MHz timestamps
     int N, H, W;   // OUTPUT size
     int strips;    // pixel strips per output row
     int total_tasks;
@@ -151,7 +168,8 @@ __device__ __forceinline__ float prelu_med3(float v, float alpha, float pin)
 constexpr int F_BNACT = 1;   // folded BatchNorm + PReLU on the way out
 constexpr int F_RES = 2;     // add the residual input before BN (ESP block, Model.py:211-213)
 constexpr int F_NOSTORE = 4; // skip the primary store (the block output is only consumed through out2)
-constexpr int F_DUAL = 8;
+constexpr int F_DUAL = 8;     // second store into a concat buffer through a second BN+PReLU: the b2 / b3
+                             // "BR over a torch.cat" stages (Model.py:359) fused into the producers
 constexpr int F_XMERGE = 256;   // TAPS == 3 only: the three horizontal taps are folded into the MFMA rows (see kernel)
 constexpr int F_S2PAIR = 512;   // STRIDE == 2, TAPS == 9: the three horizontal taps of an output pixel (inputs 2x-1..2x+1)
                                 // come from one 12-byte load instead of three stride-2 dword loads, which cost the
@@ -165,20 +183,70 @@ constexpr int F_RES_NT = 8192;    // residual loads
 constexpr int F_ST_NT = 16384;    // result stores (first output)
 constexpr int F_ST2_NT = 32768;   // F_DUAL second output
 constexpr int F_IN_NT = 65536;    // activation (B operand) loads: inputs that are read once (1x1 reduces)
-constexpr int F_X_NOLOAD = 16;  // timing experiments only (results are garbage): no activation loads in the loop
-constexpr int F_X_NOLDS = 32;   // timing experiments only: no LDS weight reads in the loop
-constexpr int F_X_NOEPI = 64;   // timing experiments only: no epilogue at all
-constexpr int F_X_STAMP2 = 4096;   // diagnostic build: [wave][64] stamps of the wave's first task: 0 start, 2+2c after the MFMA
+// Weights (A operand) straight from L2 through the operand ring instead of an LDS image: no staging phase (the 131 KB
+// image of a level-3 branch kernel took ~9 us of a ~165 us launch to fill, with every matrix pipe idle), no barrier, and
+// only the BN / PReLU parameters (+ the F_FUSE1X1 table) remain in LDS.  Every wave streams the same image in the same
+// order, so all but the first touch of a line hit the XCD's L2.
+constexpr int F_A_GLOBAL = 131072;
+// The NEXT block's 1x1 reduce computed in this kernel's epilogue: a finished output register (channel row r of the two
+// k-groups, one value per pixel column) IS the B operand of a k-step of `c1(out)`, so one extra MFMA per register
+// accumulates W_c1[:, ch] * out[ch] into a second accumulator set that is stored to the next block's reduced map when the
+// task ends.  Removes the separate 1x1 kernel and its re-read of the whole block output.
+constexpr int F_FUSE1X1 = 262144;
+constexpr int F_RES_RING = 524288;   // residual values through a half-slot register ring (see the kernel)
+constexpr int F_X_NOLOAD = 16;  // GS_DIAG timing experiments only (results are garbage): no activation loads in the loop
+constexpr int F_X_NOLDS = 32;   // GS_DIAG: no LDS weight reads in the loop
+constexpr int F_X_NOEPI = 64;   // GS_DIAG: no epilogue at all
+constexpr int F_X_STAMP2 = 4096;   // GS_DIAG: [wave][64] stamps of the wave's first task: 0 start, 2+2c after the MFMA
                                    // steps of chunk c, 3+2c after the epilogue that follows chunk c
-constexpr int F_X_STAMP = 128;  // diagnostic build: per-wave s_memrealtime stamps into a.stamp (start, staged, per-dilation, end)    // second store into a concat buffer through a second BN+PReLU: the b2 / b3
-                             // "BR over a torch.cat" stages (Model.py:359) fused into the producers
+constexpr int F_X_STAMP = 128;  // GS_DIAG: per-wave s_memrealtime stamps into a.stamp (start, staged, per-dilation, end)
+constexpr int F_X_ALL = F_X_NOLOAD | F_X_NOLDS | F_X_NOEPI | F_X_STAMP | F_X_STAMP2;
+
+// Float layout of a configuration's packed image in the weight blob: [weights NDIL*TAPS*CINP*NROW | BN scale, shift,
+// alpha (3*COUT, twice with F_DUAL) | F_FUSE1X1 table NDIL*NACC*64], rounded up to whole float4s.
+struct ConvImage {
+    int nrow, cout, w, bn, tab, total;
+};
+constexpr ConvImage conv_image(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT, bool bn, bool dual = false, bool xmerge = false,
+                               int fuse_nacc = 0)
+{
+    ConvImage im{};
+    im.nrow = xmerge ? 3 * NOUT1 : (NOUT1 > NOUT ? NOUT1 : NOUT);
+    im.cout = NOUT1 + (NDIL - 1) * NOUT;
+    im.w = NDIL * TAPS * CINP * im.nrow;
+    im.bn = (bn ? 3 * im.cout : 0) + (dual ? 3 * im.cout : 0);
+    im.tab = NDIL * fuse_nacc * 64;
+    im.total = (im.w + im.bn + im.tab + 3) / 4 * 4;
+    return im;
+}
+
+// Waves per SIMD the register allocator must leave room for: the level-2 branch kernels (16x16x4, four pixels per lane)
+// live on four waves per SIMD (<= 128 VGPRs); the forms with a fused 1x1 AND a residual (or the scalar pixel mapping)
+// need ~135 and are left at three unless CFG_L2_FORCE4 is set (they then spill ~15 registers).
+#ifndef CFG_RES_RING_DIV
+#define CFG_RES_RING_DIV 2
+#endif
+#ifndef CFG_L2_FORCE4
+#define CFG_L2_FORCE4 0
+#endif
+constexpr int conv_min_waves(int MT, int TAPS, int NDIL, int P, int FLAGS)
+{
+    if (!(MT == 16 && TAPS == 9 && NDIL == 5 && P == 4))
+        return 1;
+    if ((FLAGS & F_FUSE1X1) && ((FLAGS & F_RES) || !(FLAGS & F_VEC)) && !CFG_L2_FORCE4)
+        return 3;
+    return 4;
+}
 
 template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int G, int FLAGS>
-__global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
+__global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, FLAGS) * WAVES / 8) conv_mfma_kernel(const ConvArgs a)
 {
     constexpr bool BNACT = FLAGS & F_BNACT, RES = FLAGS & F_RES, STORE1 = !(FLAGS & F_NOSTORE), DUAL = FLAGS & F_DUAL;
     constexpr bool S2P = FLAGS & F_S2PAIR;
+    constexpr bool XMERGE_ = FLAGS & F_XMERGE;
     constexpr bool VEC = FLAGS & F_VEC;
+    constexpr bool AGL = FLAGS & F_A_GLOBAL, FUSE = FLAGS & F_FUSE1X1;
+    static_assert(kDiag || !(FLAGS & F_X_ALL), "timing / stamp variants exist in -DGS_DIAG builds only");
     constexpr int IAUX = (FLAGS & F_IN_NT) ? 2 : 0;
     constexpr int RAUX = (FLAGS & F_RES_NT) ? 2 : 0, SAUX = (FLAGS & F_ST_NT) ? 2 : 0, SAUX2 = (FLAGS & F_ST2_NT) ? 2 : 0;
     static_assert(!VEC || (STRIDE == 1 && (P == 2 || P == 4 || P == 8)), "F_VEC needs unit stride and P in {2,4,8}");
@@ -215,7 +283,17 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     unsigned long long tstamp0 = 0;
     if (FLAGS & F_X_STAMP)
         tstamp0 = __builtin_amdgcn_s_memrealtime();
-    const float *bnp = lds + NDIL * TAPS * CINP * NROW;   // [scale | shift | alpha][COUT]
+    // LDS image = the blob image (conv_image) from float LDS_SRC0 on: everything, or with F_A_GLOBAL only what follows
+    // the weights
+    constexpr int WFL = NDIL * TAPS * CINP * NROW;
+    constexpr int LDS_SRC0 = AGL ? WFL : 0;
+    static_assert(!AGL || WFL % 4 == 0, "LDS-DMA source must stay 16-byte aligned");
+    static_assert(!FUSE || (TAPS == 9 && !XMERGE_ && BNACT), "the fused 1x1 follows a branch kernel's epilogue");
+    const float *bnp = lds + (WFL - LDS_SRC0);   // [scale | shift | alpha][COUT] (x2 with F_DUAL)
+    constexpr int BNFL = (BNACT ? 3 * COUT : 0) + (DUAL ? 3 * COUT : 0);
+    const float *tab = bnp + BNFL;               // F_FUSE1X1: [NDIL][NACC][64] A operands of the next block's 1x1
+    const __amdgpu_buffer_rsrc_t rsrc_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wpack), 0, AGL ? WFL * 4 : 0, 0x00020000);
 
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -227,6 +305,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     const int vout = (kq * KSTR * a.out_sc + xl) * 4;
     const int vres = RES ? (kq * KSTR * a.res_sc + xl) * 4 : 0;
     const int vout2 = DUAL ? (kq * KSTR * a.out2_sc + xl) * 4 : 0;
+    const int vout3 = FUSE ? (kq * KSTR * a.out3_sc + xl) * 4 : 0;
+    const int prio_mode = kDiag ? a.prio_mode : 1;
 
     // Task order is (image, row, strip).  Workgroups that share an XCD (equal blockIdx % 8 under
     // round-robin dispatch: a speed assumption only) own one contiguous eighth of the tasks, and inside
@@ -284,43 +364,54 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         const __amdgpu_buffer_rsrc_t rout2 = __builtin_amdgcn_make_buffer_rsrc(
             DUAL ? a.out2 + (long long)n * a.out2_sn : a.out, 0, DUAL ? a.out2_img_bytes : 0u, 0x00020000);
         const int sout2 = DUAL ? (a.out2_off + y * a.out2_pitch + x0) * 4 : 0;
+        const __amdgpu_buffer_rsrc_t rout3 = __builtin_amdgcn_make_buffer_rsrc(
+            FUSE ? a.out3 + (long long)n * a.out3_sn : a.out, 0, FUSE ? a.out3_img_bytes : 0u, 0x00020000);
+        const int sout3 = FUSE ? (a.out3_off + y * a.out3_pitch + x0) * 4 : 0;
 
         typename M::acc_t acc[P];
+        typename M::acc_t acc2[FUSE ? P : 1];   // F_FUSE1X1: the next block's reduced map of this strip
 
         // per-lane epilogue offsets: lanes beyond the row end get an offset past num_records, which the
         // buffer range check turns into a dropped store / zero load (no exec-mask branches)
         constexpr int OOB = 0x7ffffff0;
-        int vo[P], vr[P], vo2[P];
+        int vo[P], vr[P], vo2[P], vo3[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const bool xok = x0 + (VEC ? xl : p * MT + px) < a.W;   // F_VEC: W % P == 0, a lane's pixels are all in or all out
             vo[p] = xok ? vout + (VEC ? 0 : p * MT * 4) : OOB;
             vr[p] = xok ? vres + (VEC ? 0 : p * MT * 4) : OOB;
             vo2[p] = xok ? vout2 + (VEC ? 0 : p * MT * 4) : OOB;
+            vo3[p] = xok ? vout3 + (VEC ? 0 : p * MT * 4) : OOB;
         }
         // The residual (block input) values of a whole concat slot live in dedicated registers and are
         // requested a full dilation ahead of the epilogue that adds them: fetched next to the store,
         // they cost four exposed HBM round trips per slot (measured 33 us of a 183 us launch).
-        float resv[RES ? M::NACC : 1][P];
-        auto prefetch_res = [&](int di) {
+        // F_RES_RING: only RR registers' worth of residual values is in flight -- register r's slot is refilled with register
+        // r + RR's values (of this concat slot, or of the next one) as soon as the epilogue has consumed it.  With the
+        // fused 1x1 the kernel has no room for a whole slot (16 x P registers) beside its two accumulator sets.
+        constexpr int RR = !RES ? 1 : (FLAGS & F_RES_RING) ? M::NACC / CFG_RES_RING_DIV : M::NACC;
+        float resv[RR][P];
+        auto load_res = [&](int di, int r) {   // residual values of accumulator register r of concat slot di
             if (!RES)
                 return;
             const int nout = di == 0 ? NOUT1 : NOUT;
             const int cb = di == 0 ? 0 : NOUT1 + (di - 1) * NOUT;
-#pragma unroll
-            for (int r = 0; r < M::NACC; ++r) {
-                const int ch0 = M::row(r, 0);
-                const bool live = ch0 + kq * KSTR < nout;
-                const int sr = (cb + ch0) * a.res_sc * 4 + sres;
-                if (VEC) {
-                    buf_load_vec<P, RAUX>(rres, live ? vr[0] : OOB, sr, resv[RES ? r : 0]);
-                    continue;
-                }
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    resv[RES ? r : 0][p] = __builtin_bit_cast(
-                        float, __builtin_amdgcn_raw_buffer_load_b32(rres, live ? vr[p] : OOB, sr, RAUX));
+            const int ch0 = M::row(r, 0);
+            const bool live = ch0 + kq * KSTR < nout;
+            const int sr = (cb + ch0) * a.res_sc * 4 + sres;
+            if (VEC) {
+                buf_load_vec<P, RAUX>(rres, live ? vr[0] : OOB, sr, resv[r % RR]);
+                return;
             }
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                resv[r % RR][p] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rres, live ? vr[p] : OOB, sr, RAUX));
+        };
+        auto prefetch_res = [&](int di) {   // everything the ring holds of slot di
+#pragma unroll
+            for (int r = 0; r < RR; ++r)
+                load_res(di, r);
         };
 
         // The k-loop is one flat sequence of k-steps run through a ring of D operand slots: right
@@ -378,7 +469,11 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                 aq[g * TXN + tx] = __builtin_bit_cast(float, tap + sidx + lbase);
                 return;
             }
-            aq[g * TXN + tx] = lds[((di * TAPS + tap) * CINP + sidx * KL) * NROW + lbase];
+            if (AGL)
+                aq[g * TXN + tx] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_w, lbase * 4, (((di * TAPS + tap) * CINP + sidx * KL) * NROW) * 4, 0));
+            else
+                aq[g * TXN + tx] = lds[((di * TAPS + tap) * CINP + sidx * KL) * NROW + lbase];
         };
 
         // prologue: the first chunk's activations are requested before the weights are staged, so
@@ -399,12 +494,13 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
             // weights -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR
             // round trip), every piece in flight at once; a register-staged copy loop took 9 us of a
             // 183 us launch here
-            const int pieces = (a.wfloats + 255) / 256;
+            const int pieces = (a.wfloats - LDS_SRC0 + 255) / 256;
             for (int j = wid; j < pieces; j += WAVES)
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(a.wpack + j * 256 + lane * 4),
+                    (const __attribute__((address_space(1))) void *)(a.wpack + LDS_SRC0 + j * 256 + lane * 4),
                     (__attribute__((address_space(3))) void *)(lds + j * 256), 16, 0, 0);
-            __syncthreads();
+            if (pieces > 0)
+                __syncthreads();
             staged = true;
         }
         if (idle)
@@ -415,7 +511,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         }
         // optional stagger: the two waves that share a SIMD run the same program on equal-sized tasks
         // and would otherwise reach their epilogues (no MFMA issue) together
-        if (a.stagger > 0 && task == t0) {
+        if (kDiag && a.stagger > 0 && task == t0) {
             const int ph = wid >= WAVES / 2 ? 1 : 0;   // the second wave of every SIMD starts late
             for (int z = 0; z < a.stagger * ph; ++z)
                 __builtin_amdgcn_s_sleep(16);
@@ -429,18 +525,23 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
         }
 
         prefetch_res(0);
-        if (a.prio_mode == 1) {
+        if (FUSE) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                acc2[p] = (typename M::acc_t)(0.0f);
+        }
+        if (prio_mode == 1) {
             if ((((task - t0) / tstride) + (wid >= WAVES / 2 ? 1 : 0)) & 1)
                 __builtin_amdgcn_s_setprio(1);
             else
                 __builtin_amdgcn_s_setprio(0);
-        } else if (a.prio_mode == 3 && task == t0) {
+        } else if (prio_mode == 3 && task == t0) {
             if (wid >= WAVES / 2)
                 __builtin_amdgcn_s_setprio(1);
         }
 
         for (int c = 0; c < NCHUNK; ++c) {
-            if (NDIL > 1 && c % CPD == 0 && a.prio_mode == 0) {
+            if (NDIL > 1 && c % CPD == 0 && prio_mode == 0) {
                 // The two waves of a SIMD run the same program; arbitration prefers the older one, which
                 // then finishes its task ~20 % earlier and leaves its partner alone on the pipe.
                 // Alternating static priority per dilation keeps the pair level.
@@ -559,7 +660,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                 for (int p = 0; p < P; ++p) {
                     float v = acc[p][r];
                     if (RES)
-                        v += resv[RES ? r : 0][p];
+                        v += resv[r % RR][p];
                     if (BNACT) {
                         v = v * scale + shift;
                         v = prelu_med3(v, alpha, pin);
@@ -576,12 +677,45 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
                                                                   live ? vo2[p] : OOB, so2, SAUX2);
                     }
                 }
+                if (RES && RR < M::NACC) {   // the slot just consumed is refilled at once (uniform control flow)
+                    if (r + RR < M::NACC)
+                        load_res(di, r + RR);
+                    else if (di + 1 < NDIL)
+                        load_res(di + 1, r + RR - M::NACC);
+                }
                 if (VEC && STORE1)
                     buf_store_vec<P, SAUX>(rout, live ? vo[0] + so : OOB, o1);
                 if (VEC && DUAL)
                     buf_store_vec<P, SAUX2>(rout2, live ? vo2[0] + so2 : OOB, o2);
+                if (FUSE && ch0 < nout) {   // (uniform) registers whose two channels are both beyond the slot hold nothing
+                    // k = lane's k-group <-> channel cb + ch0 + kq*KSTR; the table row is zero for channels beyond the slot
+                    const float a2 = tab[(di * M::NACC + r) * 64 + lane];
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        acc2[p] = M::run(a2, o1[p], acc2[p]);
+                }
             }
-            if (di + 1 < NDIL)
+            if (FUSE && di + 1 == NDIL) {
+                // the block's output is complete for this strip: its 1x1 reduce leaves for the next block's reduced map
+#pragma unroll
+                for (int r = 0; r < M::NACC; ++r) {
+                    const int ch0 = M::row(r, 0);
+                    if (ch0 >= a.nout3)
+                        continue;
+                    const bool live3 = ch0 + kq * KSTR < a.nout3;
+                    const int so3 = ch0 * a.out3_sc * 4 + sout3;
+                    float o3[P];
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        o3[p] = acc2[p][r];
+                        if (!VEC)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o3[p]), rout3, live3 ? vo3[p] : OOB, so3, 0);
+                    }
+                    if (VEC)
+                        buf_store_vec<P, 0>(rout3, live3 ? vo3[0] + so3 : OOB, o3);
+                }
+            }
+            if (RR == M::NACC && di + 1 < NDIL)
                 prefetch_res(di + 1);
             if ((FLAGS & F_X_STAMP) && lane == 0 && task == t0)
                 a.stamp[wg * 8 + 2 + di] = __builtin_amdgcn_s_memrealtime();
@@ -591,41 +725,59 @@ __global__ void __launch_bounds__(WAVES * 64) conv_mfma_kernel(const ConvArgs a)
     }
 }
 
-// number of floats of the LDS image for a configuration (weights, then 3*COUT BN/PReLU params)
-constexpr int conv_wfloats(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT, bool bn, bool dual = false, bool xmerge = false)
+// number of floats of a configuration's image in the weight blob (see conv_image)
+constexpr int conv_wfloats(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT, bool bn, bool dual = false, bool xmerge = false,
+                           int fuse_nacc = 0)
 {
-    const int nrow = xmerge ? 3 * NOUT1 : (NOUT1 > NOUT ? NOUT1 : NOUT);
-    const int cout = NOUT1 + (NDIL - 1) * NOUT;
-    const int n = NDIL * TAPS * CINP * nrow + (bn ? 3 * cout : 0) + (dual ? 3 * cout : 0);
-    return (n + 3) / 4 * 4;
+    return conv_image(CINP, TAPS, NDIL, NOUT1, NOUT, bn, dual, xmerge, fuse_nacc).total;
 }
+
+// Per (kernel instantiation, device): the dynamic-LDS attribute and the occupancy figure.  One process normally drives one
+// GPU, but a handle may be created on any device and from any thread, so the cache is keyed by device and locked.
+struct LaunchInfo {
+    bool attr_done = false;
+    int per_cu = 0;
+};
 
 template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int G, int FLAGS>
 gs_status launch_conv_mfma(ConvArgs a, int num_cus, hipStream_t stream)
 {
     auto kern = conv_mfma_kernel<MT, WAVES, CINP, TAPS, STRIDE, NDIL, NOUT1, NOUT, P, G, FLAGS>;
+    constexpr ConvImage im = conv_image(CINP, TAPS, NDIL, NOUT1, NOUT, FLAGS & F_BNACT, FLAGS & F_DUAL, FLAGS & F_XMERGE,
+                                        (FLAGS & F_FUSE1X1) ? Mfma<MT>::NACC : 0);
     a.strips = cdiv(a.W, (FLAGS & F_XMERGE) ? P * MT - 2 : P * MT);
     a.total_tasks = a.N * a.H * a.strips;
     a.prio_mode = 1;   // measured on the level-3 branch kernel: per dilation 0.171 ms, per task 0.167, off 0.168, fixed 0.166
+#ifdef GS_DIAG
     if (const char *e = std::getenv("GS_PRIO"))
         a.prio_mode = std::atoi(e);
     if (const char *e = std::getenv("GS_STAGGER"))
         a.stagger = std::atoi(e);
-    a.wfloats = conv_wfloats(CINP, TAPS, NDIL, NOUT1, NOUT, FLAGS & F_BNACT, FLAGS & F_DUAL, FLAGS & F_XMERGE);
-    a.lds_tile_off = (a.wfloats + 255) / 256 * 256;
+#endif
+    a.wfloats = im.total;
+    const int lds_floats = im.total - ((FLAGS & F_A_GLOBAL) ? im.w : 0);
+    a.lds_tile_off = (lds_floats + 255) / 256 * 256;
     const size_t lds_bytes = (size_t)(a.lds_tile_off + ((FLAGS & F_XMERGE) ? WAVES * MT * (P * MT + 4) : 0)) * sizeof(float);   // whole 1-KiB DMA pieces (+ tiles)
-    static bool attr_done = false;
-    if (!attr_done) {
-        GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds_bytes));
-        attr_done = true;
-    }
-    // resident workgroups per CU from the occupancy query (registers, LDS, wave slots), once per kernel
-    static int per_cu = 0;
-    if (per_cu == 0) {
-        int nb = 0;
-        GS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), WAVES * 64, lds_bytes));
-        per_cu = nb < 1 ? 1 : nb;
+    static std::mutex mu;
+    static std::map<int, LaunchInfo> by_device;
+    int dev = 0;
+    GS_HIP(hipGetDevice(&dev));
+    int per_cu;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        LaunchInfo &li = by_device[dev];
+        if (!li.attr_done) {
+            GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes));
+            li.attr_done = true;
+        }
+        // resident workgroups per CU from the occupancy query (registers, LDS, wave slots)
+        if (li.per_cu == 0) {
+            int nb = 0;
+            GS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), WAVES * 64, lds_bytes));
+            li.per_cu = nb < 1 ? 1 : nb;
+        }
+        per_cu = li.per_cu;
     }
     int grid = num_cus * per_cu;
     const int need = cdiv(a.total_tasks, WAVES);

@@ -38,14 +38,51 @@ void set_error(const char *fmt, ...)
 #define CFG_L3_C1        32, 8,   128, 1,   1,     1,   25,   25,   4, 16
 #define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 3
 #define CFG_L3_BR_P2     32, 8,   26,  9,   1,     5,   28,   25,   2, 13
+#define CFG_L3_BR_P2F    32, 8,   26,  9,   1,     5,   28,   25,   2, 3    // with the fused 1x1: 32 more accumulators
 #define CFG_DEC_CONV     16, 8,   24,  9,   1,     1,   5,    5,    8, 3
 #define CFG_DEC_CONV_XM  16, 8,   24,  3,   1,     1,   5,    5,    8, 6
 
+#ifdef GS_DIAG
 static bool getenv_flag(const char *name)
 {
     const char *e = std::getenv(name);
     return e && std::atoi(e) != 0;
 }
+static bool no_vec() { return getenv_flag("GS_NO_VEC"); }
+#else
+static constexpr bool no_vec() { return false; }
+#endif
+
+// Build-time choices, each made by measurement (profiles/README.md); the defaults are what ships.
+// F_FUSE1X1 (the next block's 1x1 reduce computed in a block's epilogue), measured at batch 32 (profiles/README.md):
+//   level 2: down-sampler 0.223 -> 0.242 ms, ESP block 0.189 -> 0.21 ms (three waves per SIMD instead of four), against
+//            0.063 ms per separate 1x1 launch: -0.084 ms per step.  On.
+//   level 3: down-sampler (no residual: the second accumulator set fits beside four pixels per lane) 0.159 -> 0.175 ms
+//            against 0.032 ms for the 1x1 launch: on.  ESP blocks: with the residual registers the second accumulator
+//            set only fits at two pixels per lane, and that form takes 0.1995 ms = exactly branch kernel + 1x1 kernel
+//            (0.167 + 0.032): no gain, off (CFG_FUSE_L3 == 2 turns it on).
+#ifndef CFG_FUSE_L3
+#define CFG_FUSE_L3 1   // 0 off, 1 down-sampler only, 2 every block
+#endif
+#ifndef CFG_FUSE_L2
+#define CFG_FUSE_L2 1
+#endif
+#ifndef CFG_L3_FUSE_P4
+#define CFG_L3_FUSE_P4 1
+#endif
+// F_A_GLOBAL (weights from L2 through the operand ring, no LDS image): level-3 ESP block 0.167 -> 0.1715 ms, level-2
+// blocks +6-10 %, stride-2 reduces +1-8 %: the 9 us staging phase it removes is cheaper than the slower loop.  Off.
+#ifndef CFG_AGL_L3
+#define CFG_AGL_L3 0
+#endif
+#ifndef CFG_AGL_L2
+#define CFG_AGL_L2 0
+#endif
+#ifndef CFG_AGL_S2
+#define CFG_AGL_S2 0    // ... and the stride-2 reduces
+#endif
+constexpr int AGL_L3 = CFG_AGL_L3 ? F_A_GLOBAL : 0, AGL_L2 = CFG_AGL_L2 ? F_A_GLOBAL : 0, AGL_S2 = CFG_AGL_S2 ? F_A_GLOBAL : 0;
+constexpr int FUSE_L3 = CFG_FUSE_L3 ? F_FUSE1X1 : 0, FUSE_L2 = CFG_FUSE_L2 ? F_FUSE1X1 : 0;
 
 // Every unit-stride conv launch exists in two pixel mappings; the vector one (F_VEC) needs the output width to be a
 // multiple of P (the 9th configuration parameter).
@@ -53,7 +90,7 @@ template <int FLAGS, int... C>
 static gs_status launch_vec(const ConvArgs &ca, int num_cus, hipStream_t s)
 {
     constexpr int cfg[] = {C...};
-    if (ca.W % cfg[8] == 0 && !getenv_flag("GS_NO_VEC"))
+    if (ca.W % cfg[8] == 0 && !no_vec())
         return launch_conv_mfma<C..., FLAGS | F_VEC>(ca, num_cus, s);
     return launch_conv_mfma<C..., FLAGS>(ca, num_cus, s);
 }
@@ -100,13 +137,18 @@ static const char *kKernelNames[K_COUNT] = {
 
 struct PackedConv {   // float offsets into the device weight blob
     long long c1 = -1, br = -1;
+    bool fused_next = false;   // br carries the F_FUSE1X1 table of the following block's c1
 };
 
 struct Model {
     int classes = 0, p = 0, q = 0;
     bool encoder_only = false;
     int device = 0, num_cus = 256;
-    int variant = 0;   // GS_VARIANT env: kernel A/B experiments (0 = shipped configuration)
+#ifdef GS_DIAG
+    int variant = 0;   // GS_VARIANT env (diagnostic builds only): kernel A/B experiments (0 = shipped configuration)
+#else
+    static constexpr int variant = 0;
+#endif
     float *dblob = nullptr;
     // offsets (floats) into dblob
     long long w1, bn1, b1, b2, b3, wcls, br, wup3, w3c, cbr0, wcc, bncc, wup2, bnu2, wconv, wconv_xm, wclassifier;
@@ -118,7 +160,7 @@ struct Model {
     void *ws = nullptr;
     size_t ws_bytes = 0;
     int ws_n = 0, ws_h = 0, ws_w = 0;
-    Act a0, inp1, inp2, r2, bb[3], a1, r3, cc[3], o2c, tt, ee, ff;
+    Act a0c, a0, inp1, inp2, r2[2], bb[3], a1, r3[2], cc[3], o2c, tt, ee, ff;
     float *prob = nullptr;   // ensemble scratch
     size_t prob_bytes = 0;
     std::map<std::string, std::pair<Act, int>> stages;   // name -> (activation, channels) of the last forward
@@ -217,8 +259,10 @@ static void pack_conv(const float *w, int cout, int cin, int k, float *dst, int 
                 dst[(((size_t)slot * taps + tap) * cinp + ci) * nrow + co] = w[((size_t)co * cin + ci) * k * k + tap];
 }
 
+// `next` names the block whose c1 (1x1 reduce of THIS block's output, Model.py:193) is computed in this block's epilogue
+// (F_FUSE1X1); empty = no fusion.
 static bool pack_block(WeightTable &t, BlobBuilder &bb, const std::string &pre, bool down, int level, PackedConv &pc,
-                       const float *dual = nullptr, int dual_coff = 0, int dual_c = 0)
+                       const float *dual = nullptr, int dual_coff = 0, int dual_c = 0, const std::string &next = "")
 {
     // level 2: cin 19 (down) / 64, n = 12, n1 = 16;  level 3: cin 131 (down) / 128, n = 25, n1 = 28
     const int n = level == 2 ? 12 : 25, n1 = level == 2 ? 16 : 28, nOut = n1 + 4 * n;
@@ -233,7 +277,10 @@ static bool pack_block(WeightTable &t, BlobBuilder &bb, const std::string &pre, 
     pack_conv(wc1, n, cin, down ? 3 : 1, bb.data.data() + pc.c1, 0, taps, cinp, n);
 
     const int rcinp = (n + kl - 1) / kl * kl;
-    pc.br = bb.reserve(conv_wfloats(rcinp, 9, 5, n1, n, true, dual != nullptr));
+    const int mt = level == 2 ? 16 : 32, nacc = level == 2 ? 4 : 16;
+    pc.fused_next = !next.empty();
+    const ConvImage im = conv_image(rcinp, 9, 5, n1, n, true, dual != nullptr, false, pc.fused_next ? nacc : 0);
+    pc.br = bb.reserve(im.total);
     static const char *dn[5] = {".d1", ".d2", ".d4", ".d8", ".d16"};
     for (int di = 0; di < 5; ++di) {
         const int co = di == 0 ? n1 : n;
@@ -242,7 +289,24 @@ static bool pack_block(WeightTable &t, BlobBuilder &bb, const std::string &pre, 
             return false;
         pack_conv(w, co, n, 3, bb.data.data() + pc.br, di, 9, rcinp, n1);
     }
-    float *bnp = bb.data.data() + pc.br + (size_t)5 * 9 * rcinp * n1;
+    if (pc.fused_next) {
+        // table[di][r][lane]: the A operand of the k-step "accumulator register r of slot di": lane = (k-group, c1 output
+        // row i); k-group kq of register r holds this block's channel cb + row(r, kq)
+        const float *w2 = t.get(next + ".c1.conv.weight", {n, nOut, 1, 1});
+        if (!t.ok)
+            return false;
+        float *tab = bb.data.data() + pc.br + im.w + im.bn;
+        for (int di = 0; di < 5; ++di) {
+            const int nout = di == 0 ? n1 : n, cb = di == 0 ? 0 : n1 + (di - 1) * n;
+            for (int r = 0; r < nacc; ++r)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane % mt, kq = lane / mt;
+                    const int row = mt == 32 ? (r & 3) + 8 * (r >> 2) + 4 * kq : kq * 4 + r;
+                    tab[(di * nacc + r) * 64 + lane] = (row < nout && i < n) ? w2[(size_t)i * nOut + cb + row] : 0.0f;
+                }
+        }
+    }
+    float *bnp = bb.data.data() + pc.br + im.w;
     // DownSamplerB: self.bn / self.act (Model.py:141-142); ESP block: self.bn = BR(nOut) (Model.py:184)
     if (dual)   // slice of the following concat's BR parameters, same [scale | shift | alpha][nOut] layout
         for (int j = 0; j < 3; ++j)
@@ -279,25 +343,27 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
     }
     const int cls = m->classes;
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8;
-    // output0_cat (planes 0..18) shares one buffer with comb_l2_l3 (planes 19..23, written by dec3): the
-    // decoder's conv CBR(19+classes, classes, 3) then reads its torch.cat input (Model.py:375) as ONE
-    // 24-plane activation with zero pad on all four sides.  The level-2 strided reduce reads planes 0..19 of
-    // it (channel count padded to a multiple of 4) with zero weights on plane 19, whose content is
-    // therefore irrelevant as long as it is finite (zero after layout, comb_l2_l3 of the last forward after).
-    m->a0 = make_act(19, 19 + cls, H1, W1, 1, 1, 32, 1);
+    // comb_l2_l3 (planes 0..cls-1, written by dec3) and output0_cat (planes cls..cls+18, written by the stem) share one
+    // buffer in the order of the decoder's torch.cat (Model.py:375), so conv CBR(19+classes, classes, 3) reads its input as
+    // ONE 24-plane activation with zero pad on all four sides.  Plane cls+19 is never written: the level-2 strided reduce
+    // reads output0_cat padded to 20 channels (a multiple of the k-step) and its padding plane must be zeros, not a
+    // plane some other stage writes (a non-finite value there would survive the zero weight).
+    m->a0c = make_act(cls + 19, cls + 20, H1, W1, 1, 1, 32, 1);
     m->inp1 = make_act(3, 3, H1, W1, 0, 0, 0, 0);
     m->inp2 = make_act(3, 3, H2, W2, 0, 0, 0, 0);
-    m->r2 = make_act(12, 12, H2, W2, 16, 16, 32, 16);  // dilation up to 16
+    for (int i = 0; i < 2; ++i)   // two reduced maps: a block reads one while its epilogue writes the next block's
+        m->r2[i] = make_act(12, 12, H2, W2, 16, 16, 32, 16);  // dilation up to 16
     for (int i = 0; i < 3; ++i)
         m->bb[i] = make_act(64, 64, H2, W2, 0, 0, 0, 0);
     m->a1 = make_act(131, 132, H2, W2, 1, 0, 32, 1);
-    m->r3 = make_act(25, 26, H3, W3, 16, 16, 32, 16);
+    for (int i = 0; i < 2; ++i)
+        m->r3[i] = make_act(25, 26, H3, W3, 16, 16, 32, 16);
     for (int i = 0; i < 3; ++i)
         m->cc[i] = make_act(128, 128, H3, W3, 0, 0, 0, 0);
     m->o2c = make_act(cls, cls, H2, W2, 0, 0, 0, 0);
     m->tt = make_act(2 * cls, 2 * cls, H2, W2, 0, 0, 0, 0);
     m->ff = make_act(cls, cls, H1, W1, 0, 0, 0, 0);
-    Act *all[] = {&m->a0, &m->inp1, &m->inp2, &m->r2, &m->bb[0], &m->bb[1], &m->bb[2], &m->a1, &m->r3,
+    Act *all[] = {&m->a0c, &m->inp1, &m->inp2, &m->r2[0], &m->r2[1], &m->bb[0], &m->bb[1], &m->bb[2], &m->a1, &m->r3[0], &m->r3[1],
                   &m->cc[0], &m->cc[1], &m->cc[2], &m->o2c, &m->tt, &m->ff};
     for (Act *a : all) {   // kernels address one image with 32-bit byte offsets (buffer soffset / voffset)
         if ((unsigned long long)a->sn * sizeof(float) >= (1ull << 31)) {
@@ -320,9 +386,11 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
         a->base = reinterpret_cast<float *>(static_cast<char *>(ws) + at);
         at += round_up(a->bytes(n) + slack, 256);
     }
-    m->ee = m->a0;   // comb_l2_l3 = planes 19.. of the output0_cat buffer
-    m->ee.base = m->a0.base + (long long)19 * m->a0.sc;
+    m->ee = m->a0c;   // comb_l2_l3 = the first planes of the concat buffer
     m->ee.C = cls;
+    m->a0 = m->a0c;   // output0_cat = the planes after it (+ the zero plane)
+    m->a0.base = m->a0c.base + (long long)cls * m->a0c.sc;
+    m->a0.C = 19;
     m->ws = ws;
     m->ws_bytes = total;
     m->ws_n = n;
@@ -396,6 +464,72 @@ static ConvArgs conv_args(const Act &in, const float *wpack, const Act &out, con
 
 static inline unsigned blocks_for(long long items) { return (unsigned)((items + 255) / 256); }
 
+#ifdef GS_DIAG
+// Timing-only diagnostics (-DGS_DIAG builds, selected by GS_VARIANT; results are wrong by construction unless noted).
+// Level-2 branch kernel, per-chunk stamps of each wave's first task -> gpurun_out/stamps2.txt (tools/stamps2.py):
+//   140 full kernel   141 no epilogue   142 no residual   143 plain stores only
+static gs_status diag_l2_stamps(Model *m, ConvArgs ca, bool last, hipStream_t s)
+{
+    static unsigned long long *stamp2 = nullptr;
+    const size_t nst = 8192 * 64;
+    if (!stamp2)
+        GS_HIP(hipMalloc(reinterpret_cast<void **>(&stamp2), nst * 8));
+    GS_HIP(hipMemsetAsync(stamp2, 0, nst * 8, s));
+    ca.stamp = stamp2;
+    gs_status st = m->variant == 140   ? launch_conv_mfma<CFG_L2_BR, F_BNACT | F_RES | F_VEC | F_X_STAMP2>(ca, m->num_cus, s)
+                   : m->variant == 141 ? launch_conv_mfma<CFG_L2_BR, F_BNACT | F_RES | F_VEC | F_X_NOEPI | F_X_STAMP2>(ca, m->num_cus, s)
+                   : m->variant == 142 ? launch_conv_mfma<CFG_L2_BR, F_BNACT | F_VEC | F_X_STAMP2>(ca, m->num_cus, s)
+                                       : launch_conv_mfma<CFG_L2_BR, F_VEC | F_X_STAMP2>(ca, m->num_cus, s);
+    if (!last) {
+        std::vector<unsigned long long> h(nst);
+        GS_HIP(hipMemcpy(h.data(), stamp2, nst * 8, hipMemcpyDeviceToHost));
+        if (FILE *f = std::fopen("gpurun_out/stamps2.txt", "w")) {
+            for (size_t w = 0; w < 8192; ++w) {
+                if (!h[w * 64 + 2]) continue;
+                for (int k = 0; k < 54; ++k) std::fprintf(f, "%llu ", h[w * 64 + k]);
+                std::fprintf(f, "\n");
+            }
+            std::fclose(f);
+        }
+    }
+    return st;
+}
+// Level-3 branch kernel:
+//   101 no epilogue   102 no epilogue, no operand loads   103 ... and no LDS reads   104 no operand loads
+//   105 per-wave stamps -> gpurun_out/stamps.txt (tools/stamps.py; results correct)   109 stores but no residual
+static gs_status diag_l3_variants(Model *m, ConvArgs ca, int i, hipStream_t s)
+{
+    switch (m->variant) {
+    case 101: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | F_X_NOEPI>(ca, m->num_cus, s);
+    case 102: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI | F_X_NOLOAD>(ca, m->num_cus, s);
+    case 103: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI | F_X_NOLOAD | F_X_NOLDS>(ca, m->num_cus, s);
+    case 104: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_X_NOLOAD>(ca, m->num_cus, s);
+    case 109: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_VEC>(ca, m->num_cus, s);
+    case 105: {
+        static unsigned long long *stamp = nullptr;
+        if (!stamp)
+            GS_HIP(hipMalloc(reinterpret_cast<void **>(&stamp), 4096 * 8 * 8));
+        GS_HIP(hipMemsetAsync(stamp, 0, 4096 * 8 * 8, s));
+        ca.stamp = stamp;
+        gs_status st = launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | POL_L3_ESP | F_X_STAMP>(ca, m->num_cus, s);
+        if (i == m->q - 1) {
+            std::vector<unsigned long long> h(2048 * 8);
+            GS_HIP(hipMemcpy(h.data(), stamp, h.size() * 8, hipMemcpyDeviceToHost));
+            if (FILE *f = std::fopen("gpurun_out/stamps.txt", "w")) {
+                for (int w = 0; w < 2048; ++w) {
+                    for (int k = 0; k < 7; ++k) std::fprintf(f, "%llu ", h[w * 8 + k]);
+                    std::fprintf(f, "\n");
+                }
+                std::fclose(f);
+            }
+        }
+        return st;
+    }
+    default: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES>(ca, m->num_cus, s);
+    }
+}
+#endif
+
 template <int CLS>
 static gs_status forward_impl(Model *m, const void *in, int in_format, int n, int H, int W, const float *mean,
                               const float *stdv, float *logits, uint8_t *mask, unsigned long long *hist, hipStream_t s)
@@ -445,9 +579,11 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
 
     // ---- level 2 (Model.py:351-357): DownSamplerB(19,64) then p ESP blocks
     L.run(K_L2_C1S, px2 * (19 * 9 * 12 * 2), [&] {
+#ifdef GS_DIAG
         if (m->variant == 41)
-            return launch_conv_mfma<CFG_L2_C1S, 0>(conv_args(m->a0, wb + m->l2_0.c1, m->r2, nullptr, n), m->num_cus, s);
-        return launch_conv_mfma<CFG_L2_C1S, F_S2PAIR | POL_L2_C1S>(conv_args(m->a0, wb + m->l2_0.c1, m->r2, nullptr, n), m->num_cus, s);
+            return launch_conv_mfma<CFG_L2_C1S, 0>(conv_args(m->a0, wb + m->l2_0.c1, m->r2[0], nullptr, n), m->num_cus, s);
+#endif
+        return launch_conv_mfma<CFG_L2_C1S, F_S2PAIR | POL_L2_C1S | AGL_S2>(conv_args(m->a0, wb + m->l2_0.c1, m->r2[0], nullptr, n), m->num_cus, s);
     });
     // b2 = BR(131) over cat([output1, output1_0, inp2]) (Model.py:359) is fused into its producers:
     // the down-sampler stores output1_0 twice (raw for the ESP blocks, b2-normalised into planes
@@ -463,60 +599,63 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         a.out2_img_bytes = (unsigned)(m->a1.sn * sizeof(float));
         return a;
     };
+    // F_FUSE1X1: the next block's reduced map is written by this block's epilogue (the two maps alternate)
+    auto with_fused = [&](ConvArgs a, const Act &r, int nout3) {
+        a.out3 = r.base;
+        a.out3_sn = r.sn;
+        a.out3_sc = r.sc;
+        a.out3_pitch = r.pitch;
+        a.out3_off = r.off;
+        a.out3_img_bytes = (unsigned)(r.sn * sizeof(float));
+        a.nout3 = nout3;
+        return a;
+    };
     const bool fuse_b2 = m->p > 0;
-    L.run(K_L2_DOWN, px2 * (12 * 9 * 64 * 2), [&] {
-        ConvArgs ca = conv_args(m->r2, wb + m->l2_0.br, m->bb[0], nullptr, n);
+    int rd2 = 0;   // index of the reduced map the next level-2 branch kernel reads
+    L.run(K_L2_DOWN, px2 * (12 * 9 * 64 * 2) + (m->l2_0.fused_next ? px2 * (64 * 12 * 2) : 0), [&] {
+        ConvArgs ca = conv_args(m->r2[rd2], wb + m->l2_0.br, m->bb[0], nullptr, n);
         if (fuse_b2) {
             ca = with_dual(ca, 64);
+#ifdef GS_DIAG
             if (m->variant == 150) return launch_vec<F_BNACT | F_DUAL, CFG_L2_BR>(ca, m->num_cus, s);
-            return launch_vec<F_BNACT | F_DUAL | POL_L2_DOWN, CFG_L2_BR_P4>(ca, m->num_cus, s);
+#endif
+            if (m->l2_0.fused_next)
+                return launch_vec<F_BNACT | F_DUAL | POL_L2_DOWN | AGL_L2 | FUSE_L2, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
+            return launch_vec<F_BNACT | F_DUAL | POL_L2_DOWN | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
         }
-        return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT), CFG_L2_BR_P4>(ca, m->num_cus, s);
+        return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
     });
+    bool have_r2 = m->l2_0.fused_next;   // the reduced map of the next block already exists
+    rd2 ^= have_r2 ? 1 : 0;
     set_stage("level2_0", m->bb[0], 64);
     int cur2 = 0;
     for (int i = 0; i < m->p; ++i) {
         const int nxt = cur2 == 1 ? 2 : 1;
         const bool last = i == m->p - 1;
-        L.run(K_L2_C1, px2 * (64 * 12 * 2), [&] {
-            ConvArgs ca = conv_args(m->bb[cur2], wb + m->l2[i].c1, m->r2, nullptr, n);
-            return launch_conv_mfma<CFG_L2_C1, POL_L2_C1>(ca, m->num_cus, s);   // 1x1: the run mapping measured no slower
-        });
-        L.run(K_L2_ESP, px2 * (12 * 9 * 64 * 2), [&] {
-            ConvArgs ca = conv_args(m->r2, wb + m->l2[i].br, m->bb[nxt], &m->bb[cur2], n);
-            // timing-only diagnostics of the level-2 branch kernel (results are wrong by construction for 141..143)
-            if (m->variant >= 140 && m->variant <= 143) {   // per-chunk stamps of each wave's first task -> gpurun_out/stamps2.txt
-                static unsigned long long *stamp2 = nullptr;
-                const size_t nst = 8192 * 64;
-                if (!stamp2) hipMalloc(reinterpret_cast<void **>(&stamp2), nst * 8);
-                hipMemsetAsync(stamp2, 0, nst * 8, s);
-                ca.stamp = stamp2;
-                gs_status st = m->variant == 140   ? launch_conv_mfma<CFG_L2_BR, F_BNACT | F_RES | F_VEC | F_X_STAMP2>(ca, m->num_cus, s)
-                               : m->variant == 141 ? launch_conv_mfma<CFG_L2_BR, F_BNACT | F_RES | F_VEC | F_X_NOEPI | F_X_STAMP2>(ca, m->num_cus, s)
-                               : m->variant == 142 ? launch_conv_mfma<CFG_L2_BR, F_BNACT | F_VEC | F_X_STAMP2>(ca, m->num_cus, s)
-                                                   : launch_conv_mfma<CFG_L2_BR, F_VEC | F_X_STAMP2>(ca, m->num_cus, s);
-                if (!last) {
-                    std::vector<unsigned long long> h(nst);
-                    hipMemcpy(h.data(), stamp2, nst * 8, hipMemcpyDeviceToHost);
-                    if (FILE *f = std::fopen("gpurun_out/stamps2.txt", "w")) {
-                        for (size_t w = 0; w < 8192; ++w) {
-                            if (!h[w * 64 + 2]) continue;
-                            for (int k = 0; k < 54; ++k) std::fprintf(f, "%llu ", h[w * 64 + k]);
-                            std::fprintf(f, "\n");
-                        }
-                        std::fclose(f);
-                    }
-                }
-                return st;
+        const bool fuse_next = m->l2[i].fused_next;
+        if (!have_r2)
+            L.run(K_L2_C1, px2 * (64 * 12 * 2), [&] {
+                ConvArgs ca = conv_args(m->bb[cur2], wb + m->l2[i].c1, m->r2[rd2], nullptr, n);
+                return launch_conv_mfma<CFG_L2_C1, POL_L2_C1>(ca, m->num_cus, s);   // 1x1: the run mapping measured no slower
+            });
+        L.run(K_L2_ESP, px2 * (12 * 9 * 64 * 2) + (fuse_next ? px2 * (64 * 12 * 2) : 0), [&] {
+            ConvArgs ca = conv_args(m->r2[rd2], wb + m->l2[i].br, m->bb[nxt], &m->bb[cur2], n);
+#ifdef GS_DIAG
+            if (m->variant >= 140 && m->variant <= 143)
+                return diag_l2_stamps(m, ca, last, s);
+            if (m->variant == 150) {
+                if (last) return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL, CFG_L2_BR>(with_dual(ca, 0), m->num_cus, s);
+                return launch_vec<F_BNACT | F_RES, CFG_L2_BR>(ca, m->num_cus, s);
             }
-            if (last) {
-                ca = with_dual(ca, 0);
-                if (m->variant == 150) return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL, CFG_L2_BR>(ca, m->num_cus, s);
-                return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST, CFG_L2_BR_P4>(ca, m->num_cus, s);
-            }
-            if (m->variant == 150) return launch_vec<F_BNACT | F_RES, CFG_L2_BR>(ca, m->num_cus, s);
-            return launch_vec<F_BNACT | F_RES | POL_L2_ESP, CFG_L2_BR_P4>(ca, m->num_cus, s);
+#endif
+            if (last)
+                return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2, CFG_L2_BR_P4>(with_dual(ca, 0), m->num_cus, s);
+            if (fuse_next)
+                return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | FUSE_L2, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
+            return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
         });
+        have_r2 = fuse_next;
+        rd2 ^= have_r2 ? 1 : 0;
         cur2 = nxt;
         if (!last)
             set_stage("level2." + std::to_string(i), m->bb[cur2], 64);
@@ -531,64 +670,60 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     set_stage("b2", m->a1, 131);
 
     // ---- level 3 (Model.py:361-366)
+    int rd3 = 0;
     L.run(K_L3_C1S, px3 * (131 * 9 * 25 * 2), [&] {
+#ifdef GS_DIAG
         if (m->variant == 41)
-            return launch_conv_mfma<CFG_L3_C1S, 0>(conv_args(m->a1, wb + m->l3_0.c1, m->r3, nullptr, n), m->num_cus, s);
-        return launch_conv_mfma<CFG_L3_C1S, F_S2PAIR | POL_L3_C1S>(conv_args(m->a1, wb + m->l3_0.c1, m->r3, nullptr, n), m->num_cus, s);
+            return launch_conv_mfma<CFG_L3_C1S, 0>(conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n), m->num_cus, s);
+#endif
+        return launch_conv_mfma<CFG_L3_C1S, F_S2PAIR | POL_L3_C1S | AGL_S2>(conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n), m->num_cus, s);
     });
-    L.run(K_L3_DOWN, px3 * (25 * 9 * 128 * 2), [&] {
-        ConvArgs ca = conv_args(m->r3, wb + m->l3_0.br, m->cc[0], nullptr, n);
-        return launch_vec<F_BNACT | POL_L3_DOWN, CFG_L3_BR>(ca, m->num_cus, s);
+    L.run(K_L3_DOWN, px3 * (25 * 9 * 128 * 2) + (m->l3_0.fused_next ? px3 * (128 * 25 * 2) : 0), [&] {
+        ConvArgs ca = conv_args(m->r3[rd3], wb + m->l3_0.br, m->cc[0], nullptr, n);
+        if (m->l3_0.fused_next) {   // no residual here: the four-pixel vector mapping still fits with the second accumulator set
+            if (ca.W % 4 == 0 && !no_vec())
+                return launch_conv_mfma<CFG_L3_BR, F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3 | F_VEC>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+            return launch_conv_mfma<CFG_L3_BR_P2F, F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+        }
+        return launch_vec<F_BNACT | POL_L3_DOWN | AGL_L3, CFG_L3_BR>(ca, m->num_cus, s);
     });
+    bool have_r3 = m->l3_0.fused_next;
+    rd3 ^= have_r3 ? 1 : 0;
     set_stage("level3_0", m->cc[0], 128);
     int cur3 = 0;
     for (int i = 0; i < m->q; ++i) {
         const int nxt = cur3 == 1 ? 2 : 1;
-        L.run(K_L3_C1, px3 * (128 * 25 * 2), [&] {
-            ConvArgs ca = conv_args(m->cc[cur3], wb + m->l3[i].c1, m->r3, nullptr, n);
-            return launch_conv_mfma<CFG_L3_C1, POL_L3_C1>(ca, m->num_cus, s);
+        const bool fuse_next = m->l3[i].fused_next;
+        if (!have_r3)
+            L.run(K_L3_C1, px3 * (128 * 25 * 2), [&] {
+                ConvArgs ca = conv_args(m->cc[cur3], wb + m->l3[i].c1, m->r3[rd3], nullptr, n);
+                return launch_conv_mfma<CFG_L3_C1, POL_L3_C1>(ca, m->num_cus, s);
+            });
+        L.run(K_L3_ESP, px3 * (25 * 9 * 128 * 2) + (fuse_next ? px3 * (128 * 25 * 2) : 0), [&] {
+            ConvArgs ca = conv_args(m->r3[rd3], wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n);
+#ifdef GS_DIAG
+            if (m->variant != 0 && m->variant != 30)
+                return diag_l3_variants(m, ca, i, s);
+#endif
+            if (fuse_next) {
+#if CFG_L3_FUSE_P4
+                // four pixels per lane with the residual through a half-slot register ring
+                if (ca.W % 4 == 0 && !no_vec())
+                    return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_RES_RING | F_VEC | POL_L3_ESP | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+#endif
+                // two consecutive pixels per lane: the second accumulator set does not fit beside four
+                if (ca.W % 2 == 0 && !no_vec())
+                    return launch_conv_mfma<CFG_L3_BR_P2F, F_BNACT | F_RES | F_VEC | POL_L3_ESP | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+                return launch_conv_mfma<CFG_L3_BR_P2F, F_BNACT | F_RES | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+            }
+            // four consecutive pixels per lane and 16-byte accesses when the width allows it (0.170 ms per
+            // launch at batch 32), else the two-run mapping with its deeper ring (0.175 ms)
+            if (ca.W % 4 == 0 && !no_vec())
+                return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | POL_L3_ESP | AGL_L3>(ca, m->num_cus, s);
+            return launch_conv_mfma<CFG_L3_BR_P2, F_BNACT | F_RES | AGL_L3>(ca, m->num_cus, s);
         });
-        L.run(K_L3_ESP, px3 * (25 * 9 * 128 * 2), [&] {
-            ConvArgs ca = conv_args(m->r3, wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n);
-            if (m->variant == 0 || m->variant == 30) {
-                // four consecutive pixels per lane and 16-byte accesses when the width allows it (0.170 ms per
-                // launch at batch 32), else the two-run mapping with its deeper ring (0.175 ms)
-                if (ca.W % 4 == 0 && !getenv_flag("GS_NO_VEC"))
-                    return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | POL_L3_ESP>(ca, m->num_cus, s);
-                return launch_conv_mfma<CFG_L3_BR_P2, F_BNACT | F_RES>(ca, m->num_cus, s);
-            }
-            // Diagnostic builds of this kernel (GS_VARIANT; results are wrong by construction except 105):
-            //   101 no epilogue   102 no epilogue, no operand loads   103 ... and no LDS reads   104 no operand loads
-            //   105 per-wave stamps -> gpurun_out/stamps.txt (tools/stamps.py)   109 stores but no residual
-            switch (m->variant) {
-            case 101: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | F_X_NOEPI>(ca, m->num_cus, s);
-            case 102: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI | F_X_NOLOAD>(ca, m->num_cus, s);
-            case 103: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI | F_X_NOLOAD | F_X_NOLDS>(ca, m->num_cus, s);
-            case 104: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_X_NOLOAD>(ca, m->num_cus, s);
-            case 109: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_VEC>(ca, m->num_cus, s);
-            case 105: {
-                static unsigned long long *stamp = nullptr;
-                if (!stamp)
-                    GS_HIP(hipMalloc(reinterpret_cast<void **>(&stamp), 4096 * 8 * 8));
-                GS_HIP(hipMemsetAsync(stamp, 0, 4096 * 8 * 8, s));
-                ca.stamp = stamp;
-                gs_status st = launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | POL_L3_ESP | F_X_STAMP>(ca, m->num_cus, s);
-                if (i == m->q - 1) {
-                    std::vector<unsigned long long> h(2048 * 8);
-                    GS_HIP(hipMemcpy(h.data(), stamp, h.size() * 8, hipMemcpyDeviceToHost));
-                    if (FILE *f = std::fopen("gpurun_out/stamps.txt", "w")) {
-                        for (int w = 0; w < 2048; ++w) {
-                            for (int k = 0; k < 7; ++k) std::fprintf(f, "%llu ", h[w * 8 + k]);
-                            std::fprintf(f, "\n");
-                        }
-                        std::fclose(f);
-                    }
-                }
-                return st;
-            }
-            default: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES>(ca, m->num_cus, s);
-            }
-        });
+        have_r3 = fuse_next;
+        rd3 ^= have_r3 ? 1 : 0;
         cur3 = nxt;
         set_stage("level3." + std::to_string(i), m->cc[cur3], 128);
     }
@@ -646,17 +781,17 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         }
     }
     L.run(K_DEC_CONV, px1 * ((19 + CLS) * 9 * CLS * 2), [&] {
-        if (m->variant != 30)
-        {
-            if (m->variant == 171)   // timing-only ablations
-                return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOEPI>(conv_args(m->a0, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
-            if (m->variant == 172)
-                return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOLOAD>(conv_args(m->a0, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
-            if (m->variant == 173)
-                return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOLOAD | F_X_NOEPI>(conv_args(m->a0, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
-            return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | POL_DEC_CONV>(conv_args(m->a0, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
-        }
-        return launch_conv_mfma<CFG_DEC_CONV, F_BNACT>(conv_args(m->a0, wb + m->wconv, m->ff, nullptr, n), m->num_cus, s);
+#ifdef GS_DIAG
+        if (m->variant == 171)   // timing-only ablations
+            return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOEPI>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
+        if (m->variant == 172)
+            return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOLOAD>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
+        if (m->variant == 173)
+            return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOLOAD | F_X_NOEPI>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
+        if (m->variant == 30)
+            return launch_conv_mfma<CFG_DEC_CONV, F_BNACT>(conv_args(m->a0c, wb + m->wconv, m->ff, nullptr, n), m->num_cus, s);
+#endif
+        return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | POL_DEC_CONV>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
     });
     set_stage("conv", m->ff, CLS);
     L.run(K_DEC4, px1 * (CLS * CLS * 4 * 2), [&] {
@@ -734,8 +869,10 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
         return GS_ERR_NODEVICE;
     }
     m.num_cus = prop.multiProcessorCount;
+#ifdef GS_DIAG
     if (const char *v = std::getenv("GS_VARIANT"))
         m.variant = std::atoi(v);
+#endif
 
     WeightTable t;
     t.blob = blob;
@@ -756,15 +893,17 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
     std::vector<float> b2f(3 * 131);
     if (!fold_bn(t, e + "b2.bn", e + "b2.act", 131, b2f.data())) return GS_ERR_INVALID;
     m.b2 = bb.push(b2f.data(), 393);
-    if (!pack_block(t, bb, e + "level2_0", true, 2, m.l2_0, p > 0 ? b2f.data() : nullptr, 64, 131)) return GS_ERR_INVALID;
+    auto next2 = [&](int i) { return (CFG_FUSE_L2 && i < p) ? e + "level2." + std::to_string(i) : std::string(); };
+    auto next3 = [&](int i) { return ((CFG_FUSE_L3 == 2 || (CFG_FUSE_L3 == 1 && i == 0)) && i < q) ? e + "level3." + std::to_string(i) : std::string(); };
+    if (!pack_block(t, bb, e + "level2_0", true, 2, m.l2_0, p > 0 ? b2f.data() : nullptr, 64, 131, next2(0))) return GS_ERR_INVALID;
     m.l2.resize(p);
     for (int i = 0; i < p; ++i)
-        if (!pack_block(t, bb, e + "level2." + std::to_string(i), false, 2, m.l2[i], i == p - 1 ? b2f.data() : nullptr, 0, 131))
+        if (!pack_block(t, bb, e + "level2." + std::to_string(i), false, 2, m.l2[i], i == p - 1 ? b2f.data() : nullptr, 0, 131, next2(i + 1)))
             return GS_ERR_INVALID;
-    if (!pack_block(t, bb, e + "level3_0", true, 3, m.l3_0)) return GS_ERR_INVALID;
+    if (!pack_block(t, bb, e + "level3_0", true, 3, m.l3_0, nullptr, 0, 0, next3(0))) return GS_ERR_INVALID;
     m.l3.resize(q);
     for (int i = 0; i < q; ++i)
-        if (!pack_block(t, bb, e + "level3." + std::to_string(i), false, 3, m.l3[i])) return GS_ERR_INVALID;
+        if (!pack_block(t, bb, e + "level3." + std::to_string(i), false, 3, m.l3[i], nullptr, 0, 0, next3(i + 1))) return GS_ERR_INVALID;
     if (!fold_bn(t, e + "b3.bn", e + "b3.act", 256, tmp.data())) return GS_ERR_INVALID;
     if (!(w = t.get(e + "classifier.conv.weight", {c, 256, 1, 1}))) return GS_ERR_INVALID;
     {
@@ -800,14 +939,14 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
         m.bnu2 = bb.push(tmp.data(), 3 * c);
         if (!(w = t.get("conv.conv.weight", {c, 19 + c, 3, 3}))) return GS_ERR_INVALID;
         {
-            // LDS image [tap][24 planes][c]: plane p < 19 is output0_cat channel p = cat channel c + p,
-            // plane 19 + j is comb_l2_l3 channel j = cat channel j (Model.py:375 cat order)
+            // LDS image [tap][24 planes][c]: the planes of the concat buffer are in the order of the reference's
+            // torch.cat([comb_l2_l3, output0_cat]) (Model.py:375), so plane = cat channel
             const int npl = 19 + c;
             m.wconv = bb.reserve(conv_wfloats(npl, 9, 1, c, c, true));
             float *dst = bb.data.data() + m.wconv;
             for (int tap = 0; tap < 9; ++tap)
                 for (int pl = 0; pl < npl; ++pl) {
-                    const int wch = pl < 19 ? c + pl : pl - 19;
+                    const int wch = pl;
                     for (int co = 0; co < c; ++co)
                         dst[((size_t)tap * npl + pl) * c + co] = w[((size_t)co * (19 + c) + wch) * 9 + tap];
                 }
@@ -817,7 +956,7 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
             float *dx = bb.data.data() + m.wconv_xm;
             for (int ty = 0; ty < 3; ++ty)
                 for (int pl = 0; pl < npl; ++pl) {
-                    const int wch = pl < 19 ? c + pl : pl - 19;
+                    const int wch = pl;
                     for (int tx = 0; tx < 3; ++tx)
                         for (int co = 0; co < c; ++co)
                             dx[((size_t)ty * npl + pl) * (3 * c) + tx * c + co] = w[((size_t)co * (19 + c) + wch) * 9 + ty * 3 + tx];
