@@ -1,0 +1,410 @@
+// Decoder tail in ONE kernel: conv = CBR(19+classes, classes, 3) over cat([comb_l2_l3, output0_cat]) ->
+// classifier ConvTranspose2d(classes, classes, 2, stride 2) -> logits -> first-max argmax -> uint8 mask ->
+// per-class pixel counts.  reference: Model.py:375-377, VisualizeResults_iou.py:128 (argmax), :151-155 (counts).
+//
+// The 3x3 convolution runs on the fp32 matrix cores (v_mfma_f32_16x16x4_f32) in the row-merged form: the MFMA rows
+// carry (horizontal tap tx, output channel o) = 15 of 16 rows, the MFMA columns are 16 consecutive input columns, K
+// walks the 24 input planes four at a time.  What is new against a per-row kernel:
+//   * a wave owns a BAND of output rows of its column strip and sweeps down it.  An input row segment is loaded ONCE
+//     and feeds three MFMAs -- the vertical taps ty = 0,1,2 of the three output rows it belongs to, held in three
+//     rolling accumulator sets -- so operand traffic is (R+2)/R x the input instead of 3x (the per-row kernel spent
+//     40 % of its time waiting on those loads);
+//   * the 18 A operands (3 vertical taps x 6 plane groups) of a lane never change: they live in registers, the k-loop
+//     reads no weights at all;
+//   * the epilogue goes on to the classifier deconvolution, the argmax and the counts, so the half-resolution
+//     5-channel map is neither written nor read back (2 x 84 MB per 32 tiles and one launch less).
+// The arithmetic (order of every accumulation chain) is the one of the kernels this replaces: masks are bit-identical.
+#pragma once
+#include <type_traits>
+
+#include "conv_mfma.h"
+#include "espnet_kernels.h"
+
+namespace gs {
+
+struct DecTailArgs {
+    // concat buffer: planes in torch.cat order, zero halo of one row / one column (Model.py:375)
+    const float *in;
+    long long in_sn;
+    int in_sc, in_pitch, in_off;
+    unsigned in_img_bytes;
+    const float *wpack;   // [3 ty][6 plane groups][64 lanes] A operands | 16: BN scale, shift, alpha [3][5] | classifier.weight [5][5][2][2]
+    float *logits;        // [N][CLS][2*H1][2*W1] or null
+    unsigned char *mask;  // [N][2*H1][2*W1] or null
+    unsigned long long *hist;   // [N][CLS] or null (zeroed by the caller)
+    float *ff;            // optional: the CBR output (stage "conv") as a gs::Act
+    long long ff_sn;
+    int ff_sc, ff_pitch, ff_off;
+    int N, H1, W1;
+    int xbase, nstrips;   // this launch covers strips of 16P-2 output columns starting at column xbase
+    int bands, R, k3;     // bands of R = 3*k3 + 2 output rows
+    int total_tasks;
+};
+
+constexpr int DT_A_FLOATS = 18 * 64;
+constexpr int DT_PACK_FLOATS = DT_A_FLOATS + 16 + 100;
+
+template <int N_>
+using IC = std::integral_constant<int, N_>;
+template <bool B_>
+using BC = std::integral_constant<bool, B_>;
+
+template <int CLS, int P>
+struct DecTailGeom {
+    static constexpr int NG = 6;             // plane groups of four (24 planes)
+    static constexpr int TS = 16 * P + 4;    // LDS tile row pitch (floats); + 4: the four k-groups of a tile write hit different banks
+    static constexpr int XS = 16 * P - 2;    // output pixels per strip
+    static_assert(CLS == 5, "row layout tx*5+o is written for five classes");
+};
+
+// (everything is local arrays + generic lambdas with compile-time indices: kept in one function body so that the
+// accumulators, the operand ring and the weights stay in registers)
+// DBG: also write the logits and the half-resolution CBR output (tests, ensemble).  A separate instantiation, so that the
+// per-lane store addresses of those outputs do not sit in registers of the mask-only kernel.
+// timing-only ablations (results wrong by construction), -DGS_DIAG builds only
+#if defined(GS_DIAG) && defined(DT_X_NOLOAD)
+constexpr bool kDtNoLoad = true;
+#else
+constexpr bool kDtNoLoad = false;
+#endif
+#if defined(GS_DIAG) && defined(DT_X_NOEPI)
+constexpr bool kDtNoEpi = true;
+#else
+constexpr bool kDtNoEpi = false;
+#endif
+#ifndef DT_PRIO
+#define DT_PRIO 1      // second half of the workgroup's waves at s_setprio 1 (see below)
+#endif
+#ifndef DT_MAIN_P
+#define DT_MAIN_P 8    // MFMA column blocks per strip of the main launch
+#endif
+#ifndef DT_MAIN_WAVES
+#define DT_MAIN_WAVES 8
+#endif
+template <int CLS, int P, bool DBG, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs a)
+{
+    using DT = DecTailGeom<CLS, P>;
+    constexpr int NG = DT::NG, TS = DT::TS, XS = DT::XS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    if (tid < 128)
+        lds[tid] = tid < 116 ? a.wpack[DT_A_FLOATS + tid] : 0.0f;
+    __syncthreads();
+    const int lane = tid & 63, j = lane & 15, kq = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *tile = lds + 128 + wid * (16 * TS);
+    static_assert(WAVES % 4 == 0, "whole waves per SIMD");
+
+    float A[3][NG];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            A[ty][g] = a.wpack[(ty * NG + g) * 64 + lane];
+    f32x4 acc[3][P];
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            acc[sl][p] = (f32x4)(0.0f);
+    float bq[NG][P];
+    const int voff = (kq * a.in_sc + j) * 4;
+    const int H = 2 * a.H1, W = 2 * a.W1;
+
+    // tasks: (image, strip, band), the bands of one column adjacent
+    // The waves that share a SIMD run the same program on equal tasks: left alone they reach their MFMA phases and their
+    // (VALU / LDS) epilogues together and the matrix pipe idles through every epilogue.  With the later half at a higher
+    // static priority the pair falls into anti-phase by itself: the preferred wave takes the pipe, and while it is in an
+    // epilogue the other one computes.
+    if (DT_PRIO && wid >= WAVES / 2)
+        __builtin_amdgcn_s_setprio(1);
+    const int nwaves = gridDim.x * WAVES;
+    for (int task = blockIdx.x * WAVES + wid; task < a.total_tasks; task += nwaves) {
+        const int col = task / a.bands;
+        const int b = task - col * a.bands;
+        const int n = col / a.nstrips;
+        const int s = col - n * a.nstrips;
+        // every band has exactly R = 3k+2 rows; the last one is shifted up to end at the image bottom and re-computes
+        // (bit-identically re-stores) the rows it shares with its neighbour, which it must not count twice
+        const int rows = a.R;
+        const int yb = b * a.R;
+        const int y0 = yb + rows <= a.H1 ? yb : a.H1 - rows;
+        const int x0 = a.xbase + XS * s;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(a.in + (long long)n * a.in_sn), 0, a.in_img_bytes, 0x00020000);
+        const int sbase = (a.in_off + x0 - 1) * 4;   // column x0-1 of row 0; row -1 is the zero halo row
+        const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
+            a.mask ? a.mask + (long long)n * H * W : reinterpret_cast<unsigned char *>(const_cast<float *>(a.in)), 0,
+            a.mask ? (unsigned)(H * W) : 0u, 0x00020000);
+        unsigned long long counts = 0;               // per-lane packed per-class counts, 12 bits each
+
+        auto fetch = [&](auto g_, int i) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_)::value;
+            const int soff = sbase + (i * a.in_pitch + 4 * g * a.in_sc) * 4;
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                bq[g][p] = kDtNoLoad ? __builtin_bit_cast(float, soff + p)
+                                     : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + p * 64, soff, 0));
+        };
+        // one input row: every plane group feeds the vertical taps whose output row lies inside the band
+        auto row_step = [&](auto ph_, auto v0_, auto v1_, auto v2_, auto more_, int inext) __attribute__((always_inline)) {
+            constexpr int PH = decltype(ph_)::value;
+            constexpr bool V0 = decltype(v0_)::value, V1 = decltype(v1_)::value, V2 = decltype(v2_)::value;
+            constexpr bool more = decltype(more_)::value;
+            auto group = [&](auto g_) __attribute__((always_inline)) {
+                constexpr int g = decltype(g_)::value;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if (V0)
+                        acc[PH][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[0][g], bq[g][p], acc[PH][p], 0, 0, 0);
+                    if (V1)
+                        acc[(PH + 2) % 3][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[1][g], bq[g][p], acc[(PH + 2) % 3][p], 0, 0, 0);
+                    if (V2)
+                        acc[(PH + 1) % 3][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[2][g], bq[g][p], acc[(PH + 1) % 3][p], 0, 0, 0);
+                }
+                // (pinned behind the MFMAs that read the slot: hoisted above them the refill needs a second register set and
+                // a copy -- with a wait for the load -- at the loop head)
+                __builtin_amdgcn_sched_barrier(0);
+                if (more)   // the slot is refilled with the same plane group of the next input row: a whole row of MFMAs to land
+                    fetch(g_, inext);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            group(IC<0>{});
+            group(IC<1>{});
+            group(IC<2>{});
+            group(IC<3>{});
+            group(IC<4>{});
+            group(IC<5>{});
+        };
+        // finished output row yo (half resolution) of accumulator set SL: tx merge -> BN -> PReLU -> deconv -> argmax -> stores
+        auto finish_row = [&](auto sl_, int yo) __attribute__((always_inline)) {
+            constexpr int SL = decltype(sl_)::value;
+            if (kDtNoEpi) {
+                float keep = 0.0f;
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    keep += acc[SL][p][0] + acc[SL][p][1] + acc[SL][p][2] + acc[SL][p][3];
+                if (keep == 123.456f)
+                    counts += 1;
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    acc[SL][p] = (f32x4)(0.0f);
+                return;
+            }
+            // the 115 epilogue constants are read from LDS every time: behind an offset the compiler cannot see through,
+            // or it keeps all of them in registers across the whole kernel (115 VGPRs the accumulators need)
+            int coff = 0;
+            asm volatile("" : "+v"(coff));
+            const float *bnl = lds + coff, *wl = lds + 16 + coff;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    tile[(4 * kq + r) * TS + 16 * p + j] = acc[SL][p][r];
+            // a zero the compiler cannot fold into the next MFMA's C operand: `mfma d, a, b, 0` writes a fresh register
+            // range and the three accumulator sets then rotate through copies at the loop head
+            float zero = 0.0f;
+            asm volatile("" : "+v"(zero));
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                acc[SL][p] = (f32x4)(zero);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // lane l owns the output pixels m = 2l, 2l+1 of the strip: out[o][m] = Z[o][m] + Z[5+o][m+1] + Z[10+o][m+2]
+            const int m0 = 2 * lane;
+            const int x = x0 + m0;
+            const bool ok = m0 < XS && x < a.W1;   // W1 and x are even: the lane's two pixels are both inside or both outside
+            const int mc = m0 < XS ? m0 : 0;
+            float f[2][CLS];
+#pragma unroll
+            for (int o = 0; o < CLS; ++o) {
+                const float2 z0 = *reinterpret_cast<const float2 *>(&tile[o * TS + mc]);
+                const float2 z1a = *reinterpret_cast<const float2 *>(&tile[(CLS + o) * TS + mc]);
+                const float2 z1b = *reinterpret_cast<const float2 *>(&tile[(CLS + o) * TS + mc + 2]);
+                const float2 z2 = *reinterpret_cast<const float2 *>(&tile[(2 * CLS + o) * TS + mc + 2]);
+                float v0 = z0.x + z1a.y + z2.x;
+                float v1 = z0.y + z1b.x + z2.y;
+                v0 = v0 * bnl[o] + bnl[CLS + o];
+                v1 = v1 * bnl[o] + bnl[CLS + o];
+                const float al = bnl[2 * CLS + o];
+                f[0][o] = prelu_med3(v0, al, prelu_pin(al));
+                f[1][o] = prelu_med3(v1, al, prelu_pin(al));
+            }
+            __builtin_amdgcn_wave_barrier();   // the tile is rewritten by the next finished row
+            if (DBG && a.ff && ok) {
+#pragma unroll
+                for (int o = 0; o < CLS; ++o)
+                    *reinterpret_cast<float2 *>(a.ff + (long long)n * a.ff_sn + (long long)o * a.ff_sc + a.ff_off + yo * a.ff_pitch + x) =
+                        make_float2(f[0][o], f[1][o]);
+            }
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                float lg[CLS][4];   // [class][pixel q, dx] = output columns 2x .. 2x+3
+                unsigned mbytes = 0;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    // one (dy, dx) phase of the deconvolution at a time: 25 weights in flight, not all 100 -- left to
+                    // itself the scheduler hoists every LDS read of the epilogue to its top, 100 registers this kernel
+                    // does not have beside its three accumulator sets
+                    __builtin_amdgcn_sched_barrier(0);
+                    float best[2] = {0.0f, 0.0f};
+                    int bi[2] = {0, 0};
+#pragma unroll
+                    for (int o = 0; o < CLS; ++o) {
+                        float w5[CLS];
+#pragma unroll
+                        for (int i = 0; i < CLS; ++i)
+                            w5[i] = wl[((i * CLS + o) * 2 + dy) * 2 + dx];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            float t = 0.0f;
+#pragma unroll
+                            for (int i = 0; i < CLS; ++i)
+                                t = fmaf(f[q][i], w5[i], t);
+                            if (DBG)
+                                lg[o][2 * q + dx] = t;
+                            if (o == 0 || t > best[q]) {   // strict '>': the first maximum wins (torch.max semantics)
+                                best[q] = t;
+                                bi[q] = o;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        mbytes |= (unsigned)bi[q] << (8 * (2 * q + dx));
+                        if (ok && yo >= yb)
+                            counts += 1ull << (12 * bi[q]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ok) {
+                    if (a.mask)   // (uniform) one 32-bit offset per lane, the row in the scalar offset
+                        __builtin_amdgcn_raw_buffer_store_b32(mbytes, rmask, 2 * x, (2 * yo + dy) * W, 2 /* nt */);
+                    if (DBG && a.logits) {
+#pragma unroll
+                        for (int o = 0; o < CLS; ++o)
+                            *reinterpret_cast<float4 *>(a.logits + (((long long)n * CLS + o) * H + 2 * yo + dy) * W + 2 * x) =
+                                make_float4(lg[o][0], lg[o][1], lg[o][2], lg[o][3]);
+                    }
+                }
+            }
+        };
+        // Step t handles input row y0-1+t: tap ty=0 goes to output row y0+t, ty=1 to y0+t-1, ty=2 to y0+t-2; after it,
+        // output row y0+t-2 is complete.  The accumulator set of output row y0+u is u % 3 and step t runs in "phase"
+        // t % 3, so every register index below is a compile-time constant.  The band is a straight line: two opening
+        // steps (no finished row yet), the steady loop three steps at a time, its remainder, two closing steps (no new
+        // row started) -- no joins inside the loop, which the register allocator needs to keep 96 accumulators in place.
+        auto do_step = [&](auto ph_, auto v0_, auto v1_, auto v2_, auto more_, int t) __attribute__((always_inline)) {
+            constexpr int PH = decltype(ph_)::value;
+            row_step(ph_, v0_, v1_, v2_, more_, y0 + t);
+            if (decltype(v2_)::value)
+                finish_row(IC<(PH + 1) % 3>{}, y0 + t - 2);
+        };
+        auto closing = [&](auto ph_, int t) __attribute__((always_inline)) {   // t == rows
+            constexpr int PH = decltype(ph_)::value;
+            do_step(ph_, BC<false>{}, BC<true>{}, BC<true>{}, BC<true>{}, t);
+            do_step(IC<(PH + 1) % 3>{}, BC<false>{}, BC<false>{}, BC<true>{}, BC<false>{}, t + 1);
+        };
+        constexpr BC<true> T{};
+        constexpr BC<false> F{};
+        fetch(IC<0>{}, y0 - 1);
+        fetch(IC<1>{}, y0 - 1);
+        fetch(IC<2>{}, y0 - 1);
+        fetch(IC<3>{}, y0 - 1);
+        fetch(IC<4>{}, y0 - 1);
+        fetch(IC<5>{}, y0 - 1);
+        do_step(IC<0>{}, T, F, F, T, 0);
+        do_step(IC<1>{}, T, T, F, T, 1);
+        int t = 2;
+        if (a.k3 > 0) {   // rows = 3*k3 + 2: the steady part is whole periods, no remainder
+            int it = a.k3;
+            do {
+                do_step(IC<2>{}, T, T, T, T, t);
+                do_step(IC<0>{}, T, T, T, T, t + 1);
+                do_step(IC<1>{}, T, T, T, T, t + 2);
+                t += 3;
+            } while (--it > 0);
+        }
+        closing(IC<2>{}, t);
+        if (a.hist) {
+            // per-class totals of the wave: unpack, butterfly-add over the 64 lanes, one atomic per class
+#pragma unroll
+            for (int k = 0; k < CLS; ++k) {
+                int c = (int)((counts >> (12 * k)) & 0xfffull);
+#pragma unroll
+                for (int sh = 32; sh >= 1; sh >>= 1)
+                    c += __shfl_xor(c, sh, 64);
+                if (lane == 0 && c)
+                    atomicAdd(&a.hist[(long long)n * CLS + k], (unsigned long long)c);
+            }
+        }
+    }
+}
+
+constexpr int DEC_TAIL_P = DT_MAIN_P;
+
+template <int P, int WAVES>
+static gs_status launch_dec_tail_p(DecTailArgs a, int num_cus, hipStream_t stream)
+{
+    using DT = DecTailGeom<5, P>;
+    a.total_tasks = a.N * a.nstrips * a.bands;
+    const size_t lds_bytes = (size_t)(128 + WAVES * 16 * DT::TS) * sizeof(float);
+    auto kern = a.logits ? dec_tail_kernel<5, P, true, WAVES> : dec_tail_kernel<5, P, false, WAVES>;
+    static std::mutex mu;
+    static std::map<int, bool> attr_done;
+    int dev = 0;
+    GS_HIP(hipGetDevice(&dev));
+    dev = dev * 2 + (a.logits ? 1 : 0);   // (device, instantiation)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_done[dev]) {
+            GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            attr_done[dev] = true;
+        }
+    }
+    int grid = cdiv(a.total_tasks, WAVES);
+    if (grid > num_cus) grid = num_cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, a);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+// Full-width strips (126 output columns, eight MFMA column blocks) in one launch; the narrow rest of the row, if any,
+// in a second one instantiated for just the column blocks it needs (its work is a few per cent of the first).
+static inline gs_status launch_dec_tail(DecTailArgs a, int num_cus, hipStream_t stream)
+{
+    constexpr int XS = DecTailGeom<5, DEC_TAIL_P>::XS;
+    const int full_strips = a.W1 / XS, rest = a.W1 - full_strips * XS;
+    // band height R = 3k+2 (the kernel's loop is whole periods of its three rolling accumulator sets): about one round of
+    // full-strip tasks over the resident waves (8 per CU) when the batch allows it; operand re-reads are (R+2)/R
+    const int slots = num_cus * DT_MAIN_WAVES;
+    const int cols = a.N * (full_strips > 0 ? full_strips : 1);
+    int bands = slots / cols;
+    if (bands < 1) bands = 1;
+    int k3 = (cdiv(a.H1, bands) - 2 + 2) / 3;   // smallest k with 3k+2 >= H1/bands
+    if (k3 < 1) k3 = 1;
+    while (k3 > 0 && 3 * k3 + 2 > a.H1) --k3;   // a band never exceeds the image (H1 >= 4; k3 == 0 gives two-row bands)
+    a.k3 = k3;
+    a.R = 3 * k3 + 2;
+    a.bands = cdiv(a.H1, a.R);
+    if (full_strips > 0) {
+        a.xbase = 0;
+        a.nstrips = full_strips;
+        gs_status st = launch_dec_tail_p<DEC_TAIL_P, DT_MAIN_WAVES>(a, num_cus, stream);
+        if (st != GS_OK) return st;
+    }
+    if (rest > 0) {
+        a.xbase = full_strips * XS;
+        a.nstrips = 1;
+        const int nrun = cdiv(rest + 2, 16);
+        if (nrun <= 1) return launch_dec_tail_p<1, 8>(a, num_cus, stream);
+        if (nrun <= 2) return launch_dec_tail_p<2, 8>(a, num_cus, stream);
+        if (nrun <= 4) return launch_dec_tail_p<4, 8>(a, num_cus, stream);
+        return launch_dec_tail_p<8, 8>(a, num_cus, stream);
+    }
+    return GS_OK;
+}
+
+}  // namespace gs

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "conv_mfma.h"
+#include "dec_tail.h"
 #include "espnet_kernels.h"
 
 namespace gs {
@@ -128,12 +129,12 @@ static gs_status launch_vec(const ConvArgs &ca, int num_cus, hipStream_t s)
 
 enum KernelId {
     K_STEM, K_POOL, K_L2_C1S, K_L2_DOWN, K_L2_C1, K_L2_ESP, K_CAT_B2, K_L3_C1S, K_L3_DOWN, K_L3_C1, K_L3_ESP,
-    K_DEC1, K_DEC2, K_DEC3, K_DEC_CONV, K_DEC4, K_COUNT
+    K_DEC1, K_DEC2, K_DEC3, K_DEC_CONV, K_DEC4, K_DEC_TAIL, K_COUNT
 };
 static const char *kKernelNames[K_COUNT] = {
     "stem_kernel", "pool_kernel", "conv_l2_reduce_s2", "conv_l2_down_branches", "conv_l2_reduce_1x1",
     "conv_l2_esp_branches", "cat_b2_kernel", "conv_l3_reduce_s2", "conv_l3_down_branches", "conv_l3_reduce_1x1",
-    "conv_l3_esp_branches", "dec1_kernel", "dec2_kernel", "dec3_kernel", "conv_dec_cbr", "dec4_kernel"};
+    "conv_l3_esp_branches", "dec1_kernel", "dec2_kernel", "dec3_kernel", "conv_dec_cbr", "dec4_kernel", "dec_tail_kernel"};
 
 struct PackedConv {   // float offsets into the device weight blob
     long long c1 = -1, br = -1;
@@ -151,7 +152,7 @@ struct Model {
 #endif
     float *dblob = nullptr;
     // offsets (floats) into dblob
-    long long w1, bn1, b1, b2, b3, wcls, br, wup3, w3c, cbr0, wcc, bncc, wup2, bnu2, wconv, wconv_xm, wclassifier;
+    long long w1, bn1, b1, b2, b3, wcls, br, wup3, w3c, cbr0, wcc, bncc, wup2, bnu2, wconv, wconv_xm, wclassifier, wtail;
     PackedConv l2_0;
     std::vector<PackedConv> l2, l3;
     PackedConv l3_0;
@@ -780,31 +781,58 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             return GS_ERR_HIP;
         }
     }
-    L.run(K_DEC_CONV, px1 * ((19 + CLS) * 9 * CLS * 2), [&] {
 #ifdef GS_DIAG
-        if (m->variant == 171)   // timing-only ablations
-            return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOEPI>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
-        if (m->variant == 172)
-            return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOLOAD>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
-        if (m->variant == 173)
-            return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOLOAD | F_X_NOEPI>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
-        if (m->variant == 30)
-            return launch_conv_mfma<CFG_DEC_CONV, F_BNACT>(conv_args(m->a0c, wb + m->wconv, m->ff, nullptr, n), m->num_cus, s);
+    if (m->variant == 30 || (m->variant >= 171 && m->variant <= 173)) {   // the two-kernel tail this build replaced, for A/B timing
+        L.run(K_DEC_CONV, px1 * ((19 + CLS) * 9 * CLS * 2), [&] {
+            if (m->variant == 171)   // timing-only ablations
+                return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOEPI>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
+            if (m->variant == 172)
+                return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOLOAD>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
+            if (m->variant == 173)
+                return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOLOAD | F_X_NOEPI>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
+            return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | POL_DEC_CONV>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
+        });
+        set_stage("conv", m->ff, CLS);
+        L.run(K_DEC4, px1 * (CLS * CLS * 4 * 2), [&] {
+            Dec4Args a{};
+            a.f = view(m->ff);
+            a.wcl = wb + m->wclassifier;
+            a.logits = logits;
+            a.mask = mask;
+            a.hist = hist;
+            a.N = n;
+            hipLaunchKernelGGL(dec4_kernel<CLS>, dim3(blocks_for(((long long)H1 * W1 + DEC4_PX - 1) / DEC4_PX), n), dim3(256), 0, s, a);
+            return GS_OK;
+        });
+        return L.st;
+    }
 #endif
-        return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | POL_DEC_CONV>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
-    });
-    set_stage("conv", m->ff, CLS);
-    L.run(K_DEC4, px1 * (CLS * CLS * 4 * 2), [&] {
-        Dec4Args a{};
-        a.f = view(m->ff);
-        a.wcl = wb + m->wclassifier;
+    L.run(K_DEC_TAIL, px1 * ((19 + CLS) * 9 * CLS * 2) + px1 * (CLS * CLS * 4 * 2), [&] {
+        DecTailArgs a{};
+        a.in = m->a0c.base;
+        a.in_sn = m->a0c.sn;
+        a.in_sc = m->a0c.sc;
+        a.in_pitch = m->a0c.pitch;
+        a.in_off = m->a0c.off;
+        a.in_img_bytes = (unsigned)(m->a0c.sn * sizeof(float));
+        a.wpack = wb + m->wtail;
         a.logits = logits;
         a.mask = mask;
         a.hist = hist;
+        if (logits) {   // debug / test path: the half-resolution CBR output is kept as stage "conv"
+            a.ff = m->ff.base;
+            a.ff_sn = m->ff.sn;
+            a.ff_sc = m->ff.sc;
+            a.ff_pitch = m->ff.pitch;
+            a.ff_off = m->ff.off;
+        }
         a.N = n;
-        hipLaunchKernelGGL(dec4_kernel<CLS>, dim3(blocks_for(((long long)H1 * W1 + DEC4_PX - 1) / DEC4_PX), n), dim3(256), 0, s, a);
-        return GS_OK;
+        a.H1 = H1;
+        a.W1 = W1;
+        return launch_dec_tail(a, m->num_cus, s);
     });
+    if (logits)
+        set_stage("conv", m->ff, CLS);
     return L.st;
 }
 
@@ -965,6 +993,23 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
         }
         if (!(w = t.get("classifier.weight", {c, c, 2, 2}))) return GS_ERR_INVALID;
         m.wclassifier = bb.push(w, (size_t)c * c * 4);
+        {
+            // dec_tail image: A operands [ty][plane group][lane] (lane = k-group * 16 + MFMA row, row = tx*c + o),
+            // then BN scale / shift / alpha of conv, then classifier.weight
+            const float *wc = t.get("conv.conv.weight", {c, 19 + c, 3, 3});
+            if (!wc) return GS_ERR_INVALID;
+            m.wtail = bb.reserve(DT_PACK_FLOATS);
+            float *dt = bb.data.data() + m.wtail;
+            for (int ty = 0; ty < 3; ++ty)
+                for (int g = 0; g < 6; ++g)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int rho = lane & 15, ch = 4 * g + (lane >> 4);
+                        dt[(ty * 6 + g) * 64 + lane] =
+                            rho < 3 * c ? wc[(((size_t)(rho % c) * (19 + c) + ch) * 3 + ty) * 3 + rho / c] : 0.0f;
+                    }
+            if (!fold_bn(t, "conv.bn", "conv.act", c, dt + DT_A_FLOATS)) return GS_ERR_INVALID;
+            std::memcpy(dt + DT_A_FLOATS + 16, w, sizeof(float) * c * c * 4);
+        }
     }
     bb.reserve(512);   // tail guard: LDS-DMA staging reads whole 1-KiB pieces
     GS_HIP(hipMalloc(reinterpret_cast<void **>(&m.dblob), bb.data.size() * sizeof(float)));
