@@ -48,6 +48,7 @@ PROTOTYPES = {
     "gs_espnet_segment_host": (_I, [_P, _P, _I, _I, _I, _FP, _FP, _I, _P, _P]),
     "gs_espnet_ensemble_forward": (_I, [ctypes.POINTER(_P), _I, _P, _I, _I, _I, _FP, _FP, _P, _P, _P]),
     "gs_espnet_read_stage": (_I, [_P, ctypes.c_char_p, _I, _P, ctypes.c_size_t, ctypes.POINTER(_I * 3)]),
+    "gs_espnet_block_forward": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "gs_espnet_profile_enable": (_I, [_P, _I]),
     "gs_espnet_profile_read": (_I, [_P, ctypes.POINTER(KernelTime), _I, ctypes.POINTER(_I)]),
     "gs_crop_preprocess": (_I, [_P, _I, _I, _FP, _FP, _I, _I, _P, _P]),
@@ -56,6 +57,7 @@ PROTOTYPES = {
     "gs_arc_length_closed": (ctypes.c_double, [_P, _I]),
     "gs_approx_poly_closed": (_I, [_P, _I, ctypes.c_double, _P]),
     "gs_wsi_paste_max": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _P]),
+    "gs_wsi_paste_max_lut": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "gs_overlay_classmap": (_I, [_P, _P, _I, _I, _P, _I, ctypes.c_float, ctypes.c_float, _P, _P]),
     "gs_confusion_u8": (_I, [_P, _P, ctypes.c_longlong, _I, _P, _P]),
     "gs_conv2d_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P]),

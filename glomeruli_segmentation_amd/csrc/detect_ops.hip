@@ -351,8 +351,9 @@ __global__ void __launch_bounds__(256) crop_preprocess_kernel(const CropArgs a)
     const int ox = idx % a.ow, oy = idx / a.ow;
     int x0, x1, y0, y1;
     float wx, wy;
-    linear_tap(ox, (double)a.w / (double)a.ow, a.w, x0, x1, wx);
-    linear_tap(oy, (double)a.h / (double)a.oh, a.h, y0, y1, wy);
+    // OpenCV's own expression: scale = 1. / inv_scale with inv_scale = (double)dst / src
+    linear_tap(ox, 1.0 / ((double)a.ow / (double)a.w), a.w, x0, x1, wx);
+    linear_tap(oy, 1.0 / ((double)a.oh / (double)a.h), a.h, y0, y1, wy);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         auto norm = [&](int y, int x) {
@@ -374,8 +375,9 @@ mask_nearest_kernel(const unsigned char *src, int h, int w, int oh, int ow, unsi
     if (idx >= oh * ow)
         return;
     const int ox = idx % ow, oy = idx / ow;
-    int sx = (int)floor((double)ox * ((double)w / (double)ow));
-    int sy = (int)floor((double)oy * ((double)h / (double)oh));
+    // OpenCV resizeNN: ifx = 1. / fx with fx = (double)dst / src; sx = min(cvFloor(x * ifx), src - 1)
+    int sx = (int)floor((double)ox * (1.0 / ((double)ow / (double)w)));
+    int sy = (int)floor((double)oy * (1.0 / ((double)oh / (double)h)));
     sx = sx < w - 1 ? sx : w - 1;
     sy = sy < h - 1 ? sy : h - 1;
     out[idx] = src[(long long)sy * w + sx];
@@ -393,6 +395,31 @@ wsi_paste_max_kernel(unsigned char *map, int map_h, int map_w, int ds, const uns
     const int X = X0 + idx % nx, Y = Y0 + idx / nx;
     const int cx = X * ds - x1, cy = Y * ds - y1;
     if (X < 0 || Y < 0 || X >= map_w || Y >= map_h || cx < 0 || cy < 0 || cx >= w || cy >= h)
+        return;
+    const unsigned char v = crop[(long long)cy * w + cx];
+    unsigned char *dst = map + (long long)Y * map_w + X;
+    if (v > *dst)
+        *dst = v;
+}
+
+// The same paste with the level-0 sample position of every map column / row given by a table (-1 = the reference
+// never writes that column / row): reproduces the reference's 2400-px window walk exactly, including its partial edge
+// windows, whose INTER_NEAREST step is not 8 (eval_wsi_segmentation.py:229), and the windows it skips (:386).
+__global__ void __launch_bounds__(256)
+wsi_paste_max_lut_kernel(unsigned char *map, int map_h, int map_w, const int *sx, const int *sy, const unsigned char *crop, int h,
+                         int w, int x1, int y1, int X0, int Y0, int nx, int ny)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nx * ny)
+        return;
+    const int X = X0 + idx % nx, Y = Y0 + idx / nx;
+    if (X < 0 || Y < 0 || X >= map_w || Y >= map_h)
+        return;
+    const int px = sx[X], py = sy[Y];
+    if (px < 0 || py < 0)
+        return;
+    const int cx = px - x1, cy = py - y1;
+    if (cx < 0 || cy < 0 || cx >= w || cy >= h)
         return;
     const unsigned char v = crop[(long long)cy * w + cx];
     unsigned char *dst = map + (long long)Y * map_w + X;
@@ -480,6 +507,21 @@ gs_status gs_wsi_paste_max(uint8_t *slide_map, int map_h, int map_w, int ds, con
         return GS_OK;
     hipLaunchKernelGGL(wsi_paste_max_kernel, dim3((nx * ny + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
                        slide_map, map_h, map_w, ds, crop_mask, h, w, x1, y1, X0, Y0, nx, ny);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+gs_status gs_wsi_paste_max_lut(uint8_t *slide_map, int map_h, int map_w, int ds, const int *sx_lut, const int *sy_lut,
+                               const uint8_t *crop_mask, int h, int w, int x1, int y1, void *hip_stream)
+{
+    GS_REQUIRE(slide_map && crop_mask && sx_lut && sy_lut, "gs_wsi_paste_max_lut: null pointer");
+    GS_REQUIRE(map_h > 0 && map_w > 0 && ds > 0 && h > 0 && w > 0, "gs_wsi_paste_max_lut: bad size");
+    // candidate map cells: the table is monotone with steps of >= ds, so the crop's cells lie within one cell of its
+    // footprint on the regular grid; the kernel tests each candidate against the table
+    const int X0 = x1 / ds - 1, Y0 = y1 / ds - 1;
+    const int nx = (x1 + w) / ds + 2 - X0, ny = (y1 + h) / ds + 2 - Y0;
+    hipLaunchKernelGGL(wsi_paste_max_lut_kernel, dim3((nx * ny + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                       slide_map, map_h, map_w, sx_lut, sy_lut, crop_mask, h, w, x1, y1, X0, Y0, nx, ny);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -1101,6 +1101,65 @@ gs_status gs_espnet_read_stage(gs_espnet *h, const char *stage, int image, float
     return GS_OK;
 }
 
+gs_status gs_espnet_block_forward(gs_espnet *h, int kind, int level, int index, const float *in, int height, int width,
+                                  float *out)
+{
+    GS_REQUIRE(h && in && out, "gs_espnet_block_forward: null argument");
+    GS_REQUIRE((kind == 0 || kind == 1) && (level == 2 || level == 3), "kind must be 0/1 and level 2/3");
+    GS_REQUIRE(height >= 1 && width >= 1, "empty input");
+    Model &m = h->m;
+    GS_REQUIRE(kind == 1 || (index >= 0 && index < (level == 2 ? m.p : m.q)), "no ESP block %d at level %d", index, level);
+    GS_REQUIRE(kind == 0 || (height % 2 == 0 && width % 2 == 0), "the down-sampler needs an even input size");
+    // the tile size whose pyramid has this block at the given size
+    const int up = kind == 0 ? (level == 2 ? 4 : 8) : (level == 2 ? 2 : 4);
+    gs_status st = layout_workspace(&m, 1, height * up, width * up);
+    if (st != GS_OK) return st;
+    const float *wb = m.dblob;
+    const Act &src = kind == 0 ? (level == 2 ? m.bb[0] : m.cc[0]) : (level == 2 ? m.a0 : m.a1);
+    const Act &dst = level == 2 ? (kind == 0 ? m.bb[1] : m.bb[0]) : (kind == 0 ? m.cc[1] : m.cc[0]);
+    const Act &red = level == 2 ? m.r2[0] : m.r3[0];
+    const int cin = kind == 0 ? (level == 2 ? 64 : 128) : (level == 2 ? 19 : 131);
+    const int cout = level == 2 ? 64 : 128;
+    GS_REQUIRE(src.H == height && src.W == width, "internal: workspace level size mismatch");
+    const size_t nin = (size_t)cin * height * width, nout = (size_t)cout * dst.H * dst.W;
+    float *tmp = nullptr;
+    GS_HIP(hipMalloc(reinterpret_cast<void **>(&tmp), (nin > nout ? nin : nout) * sizeof(float)));
+    gs_status rc = GS_OK;
+    hipStream_t s = nullptr;
+    auto body = [&]() -> gs_status {
+        GS_HIP(hipMemcpy(tmp, in, nin * sizeof(float), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(pad_kernel, dim3(blocks_for((long long)nin)), dim3(256), 0, s, view(src), 0, cin, tmp);
+        const PackedConv &pc = kind == 1 ? (level == 2 ? m.l2_0 : m.l3_0) : (level == 2 ? m.l2[index] : m.l3[index]);
+        gs_status r;
+        if (level == 2) {
+            r = kind == 1 ? launch_conv_mfma<CFG_L2_C1S, F_S2PAIR | POL_L2_C1S | AGL_S2>(conv_args(src, wb + pc.c1, red, nullptr, 1), m.num_cus, s)
+                          : launch_conv_mfma<CFG_L2_C1, POL_L2_C1>(conv_args(src, wb + pc.c1, red, nullptr, 1), m.num_cus, s);
+            if (r != GS_OK) return r;
+            r = kind == 1 ? launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2, CFG_L2_BR_P4>(conv_args(red, wb + pc.br, dst, nullptr, 1), m.num_cus, s)
+                          : launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2, CFG_L2_BR_P4>(conv_args(red, wb + pc.br, dst, &src, 1), m.num_cus, s);
+        } else {
+            r = kind == 1 ? launch_conv_mfma<CFG_L3_C1S, F_S2PAIR | POL_L3_C1S | AGL_S2>(conv_args(src, wb + pc.c1, red, nullptr, 1), m.num_cus, s)
+                          : launch_conv_mfma<CFG_L3_C1, POL_L3_C1>(conv_args(src, wb + pc.c1, red, nullptr, 1), m.num_cus, s);
+            if (r != GS_OK) return r;
+            if (kind == 1)
+                r = launch_vec<F_BNACT | POL_L3_DOWN | AGL_L3, CFG_L3_BR>(conv_args(red, wb + pc.br, dst, nullptr, 1), m.num_cus, s);
+            else if (dst.W % 4 == 0)
+                r = launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | POL_L3_ESP | AGL_L3>(conv_args(red, wb + pc.br, dst, &src, 1), m.num_cus, s);
+            else
+                r = launch_conv_mfma<CFG_L3_BR_P2, F_BNACT | F_RES | AGL_L3>(conv_args(red, wb + pc.br, dst, &src, 1), m.num_cus, s);
+        }
+        if (r != GS_OK) return r;
+        hipLaunchKernelGGL(unpad_kernel, dim3(blocks_for((long long)nout)), dim3(256), 0, s, view(dst), 0, cout, tmp);
+        GS_HIP(hipGetLastError());
+        GS_HIP(hipMemcpy(out, tmp, nout * sizeof(float), hipMemcpyDeviceToHost));
+        return GS_OK;
+    };
+    rc = body();
+    hipFree(tmp);
+    m.stages.clear();   // the workspace no longer holds a forward's stages
+    return rc;
+}
+
 gs_status gs_espnet_profile_enable(gs_espnet *h, int on)
 {
     GS_REQUIRE(h, "null handle");

@@ -604,4 +604,16 @@ __global__ void __launch_bounds__(256) unpad_kernel(const ActV t, int n, int C, 
     dst[idx] = *at(t, n, c, y, x);
 }
 
+// inverse of unpad_kernel: dense CHW -> interior of one image of a padded activation (test hook gs_espnet_block_forward)
+__global__ void __launch_bounds__(256) pad_kernel(const ActV t, int n, int C, const float *src)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)C * t.H * t.W)
+        return;
+    const int x = (int)(idx % t.W);
+    const int y = (int)((idx / t.W) % t.H);
+    const int c = (int)(idx / ((long long)t.W * t.H));
+    *at(t, n, c, y, x) = src[idx];
+}
+
 }  // namespace gs

@@ -160,6 +160,17 @@ class EspnetEngine:
                                                      out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(dims)))
         return out
 
+    def block_forward(self, kind, level, index, x):
+        """One block of the trunk on a host CHW fp32 array (test hook; kind 0 = ESP block, 1 = DownSamplerB)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        c, h, w = x.shape
+        cout = 64 if level == 2 else 128
+        out = np.empty((cout, h, w) if kind == 0 else (cout, h // 2, w // 2), dtype=np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gs_espnet_block_forward(self.handle, kind, level, index, x.ctypes.data_as(ctypes.c_void_p),
+                                                        h, w, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     def profile(self, on):
         _lib.check(self.lib.gs_espnet_profile_enable(self.handle, 1 if on else 0))
 

@@ -1,9 +1,7 @@
-"""Host image helpers the per-patch driver needs around the GPU pass.  cv2 is not installed in
-this image, so the two ``cv2.resize`` calls of the reference loop
-(module/espnet/test/VisualizeResults_iou.py:114 INTER_LINEAR on float32, :129 INTER_NEAREST) are
-restated here from OpenCV's documented sampling rules; both are identities when the crop already
-has the network size (every BASELINE config).  Parity for non-identity resizes is unpinned (no
-executable cv2 here) and says so in DESIGN.md.
+"""Host image helpers the per-patch driver needs around the GPU pass: file I/O in cv2's channel order, the
+reference's palette, addWeighted and the Cityscapes relabel.  The two ``cv2.resize`` calls of the reference loop
+(module/espnet/test/VisualizeResults_iou.py:114, :129) run on the GPU (gs_crop_preprocess / gs_mask_resize_nearest);
+their CPU restatement is test infrastructure and lives in oracle/image_oracle.py.
 """
 import numpy as np
 from PIL import Image
@@ -24,56 +22,6 @@ def imread_bgr(path):
 
 def imwrite_bgr(path, bgr):
     Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(path)
-
-
-def _linear_taps(dst, src):
-    scale = src / float(dst)
-    f = ((np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)   # half-pixel centres, no antialias
-    i0 = np.floor(f).astype(np.int64)
-    w1 = f - i0.astype(np.float32)
-    lo = i0 < 0
-    i0[lo] = 0
-    w1[lo] = 0.0
-    hi = i0 >= src - 1
-    i0[hi] = src - 1
-    w1[hi] = 0.0
-    i1 = np.minimum(i0 + 1, src - 1)
-    return i0, i1, w1
-
-
-def resize_linear_f32(img, width, height):
-    """cv2.resize(img, (width, height)) for a float32 HxWxC image, INTER_LINEAR."""
-    h, w = img.shape[:2]
-    if (w, h) == (width, height):
-        return img.copy()
-    x0, x1, wx = _linear_taps(width, w)
-    y0, y1, wy = _linear_taps(height, h)
-    one = np.float32(1.0)
-    rows = img[:, x0] * (one - wx)[None, :, None] + img[:, x1] * wx[None, :, None]   # horizontal pass first
-    out = rows[y0] * (one - wy)[:, None, None] + rows[y1] * wy[:, None, None]
-    return out.astype(np.float32)
-
-
-def resize_nearest(img, width, height):
-    """cv2.resize(..., interpolation=cv2.INTER_NEAREST): src = min(floor(dst * src/dst), src-1)."""
-    h, w = img.shape[:2]
-    if (w, h) == (width, height):
-        return img.copy()
-    xs = np.minimum(np.floor(np.arange(width) * (w / float(width))).astype(np.int64), w - 1)
-    ys = np.minimum(np.floor(np.arange(height) * (h / float(height))).astype(np.int64), h - 1)
-    return img[ys][:, xs]
-
-
-def normalise_then_resize(bgr_u8, mean, std, width, height):
-    """VisualizeResults_iou.py:107-116 for a crop that is NOT already network-sized: the reference
-    normalises at crop resolution, resizes the float image, then divides by 255.  Returns fp32
-    CHW ready for the GS_IN_F32_NCHW entry."""
-    img = bgr_u8.astype(np.float32)
-    img -= np.asarray(mean, dtype=np.float32)
-    img /= np.asarray(std, dtype=np.float32)
-    img = resize_linear_f32(img, width, height)
-    img /= 255
-    return np.ascontiguousarray(img.transpose(2, 0, 1))
 
 
 def colourise(class_map):

@@ -71,14 +71,16 @@ def metric_right(hist):
     return overall, per_acc, per_iu, np.nanmean(per_iu)
 
 
-def segment_images(engine, images, mean, std, width, height, batch):
-    """images: list of HxWx3 uint8 BGR crops of any size -> list of class maps at crop size.
+def segment_images(engine, images, mean, std, width, height, batch, want_net_maps=False):
+    """images: list of HxWx3 uint8 BGR crops of any size -> list of class maps at crop size
+    (with want_net_maps: (crop-size maps, network-resolution maps) -- the reference scores the latter, :202).
     Crops already at network size go down the fused uint8 path (normalisation in the first kernel);
     others are normalised + resized on the GPU exactly in the reference's order (:107-116).
     With an encoder-only engine (modelType 2) every crop takes the second route and the 1/8-scale
     logits are upsampled x8 bilinearly as the reference's `up` module does (:259-261,125-126)."""
     import torch
     out = [None] * len(images)
+    net = [None] * len(images)
     enc = engine.encoder_only
     native = [] if enc else [i for i, im in enumerate(images) if im.shape[:2] == (height, width)]
     other = [i for i in range(len(images)) if enc or images[i].shape[:2] != (height, width)]
@@ -89,6 +91,7 @@ def segment_images(engine, images, mean, std, width, height, batch):
         mask = mask.cpu().numpy()
         for j, i in enumerate(idx):
             out[i] = mask[j]
+            net[i] = mask[j]
     from .engine import crop_preprocess, mask_resize_nearest
     for s in range(0, len(other), batch):
         idx = other[s:s + batch]
@@ -99,10 +102,13 @@ def segment_images(engine, images, mean, std, width, height, batch):
         if enc:
             logits = torch.nn.functional.interpolate(logits, scale_factor=8, mode="bilinear", align_corners=False)
         cls = logits.max(1)[1].byte()       # :128
+        cls_host = cls.cpu().numpy() if want_net_maps else None
         for j, i in enumerate(idx):
             h, w = images[i].shape[:2]
             out[i] = mask_resize_nearest(cls[j], h, w).cpu().numpy()    # :129
-    return out
+            if want_net_maps:
+                net[i] = cls_host[j]
+    return (out, net) if want_net_maps else out
 
 
 def evaluate(args, engine, rgb_list, label_list):
@@ -115,8 +121,8 @@ def evaluate(args, engine, rgb_list, label_list):
     for s in range(0, len(rgb_list), args.batch):
         names = rgb_list[s:s + args.batch]
         images = [imageops.imread_bgr(n) for n in names]
-        masks = segment_images(engine, images, mean, std, args.inWidth, args.inHeight, args.batch)
-        for img_name, label_name, img, cmap in zip(names, label_list[s:s + args.batch], images, masks):
+        masks, net_maps = segment_images(engine, images, mean, std, args.inWidth, args.inHeight, args.batch, want_net_maps=True)
+        for img_name, label_name, img, cmap, net_map in zip(names, label_list[s:s + args.batch], images, masks, net_maps):
             patient = os.path.basename(os.path.dirname(img_name))
             name = os.path.basename(img_name)
             stem = name.rsplit(".", 1)[0]
@@ -143,10 +149,16 @@ def evaluate(args, engine, rgb_list, label_list):
                 assert os.path.basename(img_name) == os.path.basename(label_name)
                 lab = np.asarray(Image.open(label_name))
                 assert lab.shape[:2] == img.shape[:2]
-                # the reference scores at network resolution (:195-203): nearest-resize both
-                lab_r = imageops.resize_nearest(lab, args.inWidth, args.inHeight)
-                pred_r = imageops.resize_nearest(cmap, args.inWidth, args.inHeight) if cmap.shape != lab_r.shape else cmap
-                hist = confusion(pred_r.ravel(), lab_r.ravel(), args.classes)
+                # the reference scores at network resolution (:195-203): the label is nearest-resized to the network
+                # size and compared with img_out.max(1)[1] itself, NOT with the map that went to crop size and back
+                if lab.shape[:2] == (args.inHeight, args.inWidth):
+                    lab_r = lab
+                else:
+                    import torch
+                    from .engine import mask_resize_nearest
+                    lab_r = mask_resize_nearest(torch.from_numpy(np.array(lab, dtype=np.uint8)).to(engine.device),
+                                                args.inHeight, args.inWidth).cpu().numpy()      # :195 cv2.resize INTER_NEAREST
+                hist = confusion(net_map.ravel(), lab_r.ravel(), args.classes)
                 total_hist = hist if total_hist is None else total_hist + hist
                 uniq = np.unique(lab_r)
                 for v in uniq.tolist():

@@ -37,22 +37,33 @@ def segment_sharded(compute, load_tiles, total, rank, world, dist=None, device=N
     compute(tiles uint8 [n,H,W,3]) -> (masks uint8 [n,H,W], counts int64 [n,classes])  (numpy or torch)
     load_tiles(lo, hi) -> uint8 [hi-lo,H,W,3] for global tile indices [lo, hi)
     Returns (masks [total,H,W] on rank 0 else None, counts_total int64 [classes] on every rank).
+
+    Masks that `compute` returns as device tensors stay on the device: they are concatenated there and handed to
+    the collective as they are (backend "nccl" = RCCL: GPU to GPU over xGMI); only the gathered result on rank 0
+    is copied to the host.  With the "gloo" backend (CPU tests, one-GPU rehearsal) device tensors are staged
+    through host memory because that backend cannot take them.
     """
     import torch
     lo, hi = rank_range(total, rank, world)
-    masks, counts = [], np.zeros(classes, dtype=np.int64)
+    masks = []
+    counts = None
     for s in range(lo, hi, batch):
         e = min(s + batch, hi)
         m, c = compute(load_tiles(s, e))
-        m = m.cpu().numpy() if hasattr(m, "cpu") else np.asarray(m)
-        c = c.cpu().numpy() if hasattr(c, "cpu") else np.asarray(c)
+        m = m if isinstance(m, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(m))
+        c = c if isinstance(c, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(c))
         masks.append(m)
-        counts += c.reshape(-1, classes).sum(0).astype(np.int64)
-    local = np.concatenate(masks, 0) if masks else None
+        csum = c.reshape(-1, classes).sum(0).to(torch.int64)
+        counts = csum if counts is None else counts + csum
+    local = torch.cat(masks, 0) if masks else None
+    if counts is None:
+        counts = torch.zeros(classes, dtype=torch.int64)
     if world == 1 or dist is None:
-        return local, counts
-    dev = device if device is not None else torch.device("cpu")
-    tot = torch.from_numpy(counts).to(dev)
+        return (local.cpu().numpy() if local is not None else None), counts.cpu().numpy()
+    host_staged = dist.get_backend() == "gloo"
+    dev = torch.device("cpu") if host_staged else (
+        torch.device(device) if device is not None else (local.device if local is not None else torch.device("cpu")))
+    tot = counts.to(dev)
     dist.all_reduce(tot)                                   # per-class pixel totals of the whole slide
     out = None
     if gather_masks:
@@ -63,13 +74,13 @@ def segment_sharded(compute, load_tiles, total, rank, world, dist=None, device=N
         longest = max(rank_range(total, r, world)[1] - rank_range(total, r, world)[0] for r in range(world))
         buf = torch.zeros((longest, th, tw), dtype=torch.uint8, device=dev)
         if local is not None and len(local):
-            buf[:hi - lo] = torch.from_numpy(local).to(dev)
+            buf[:hi - lo] = local.to(dev)                  # device-to-device when the masks already live there
         recv = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
         dist.gather(buf, recv, dst=0)
         if rank == 0:
             parts = []
             for r in range(world):
                 rlo, rhi = rank_range(total, r, world)
-                parts.append(recv[r][:rhi - rlo].cpu().numpy())
-            out = np.concatenate(parts, 0)
+                parts.append(recv[r][:rhi - rlo])
+            out = torch.cat(parts, 0).cpu().numpy()        # the one device-to-host copy, on rank 0
     return out, tot.cpu().numpy()

@@ -110,6 +110,13 @@ gs_status gs_mask_resize_nearest(const uint8_t *mask, int h, int w, int out_h, i
  * gs_confusion_u8: iouEval.fast_hist (IOUEval.py:19-21): hist[classes*gt + pred] += 1 for gt < classes. */
 gs_status gs_wsi_paste_max(uint8_t *slide_map, int map_h, int map_w, int ds, const uint8_t *crop_mask, int h, int w,
                            int x1, int y1, void *hip_stream);
+/* The reference's own window walk (eval_wsi_segmentation.py:372-393): sx_lut[X] / sy_lut[Y] (device, map_w / map_h ints)
+ * give the level-0 column / row that map column X / row Y shows, -1 where the reference writes nothing.  Inside full
+ * 2400-px windows that is ds*X; in the partial windows at the right / bottom edge the INTER_NEAREST step of :229 is
+ * (window size) / int(window size / ds); windows the reference skips (`ymax > slide_width`, :386) stay empty.
+ * composite.reference_window_luts builds the tables. */
+gs_status gs_wsi_paste_max_lut(uint8_t *slide_map, int map_h, int map_w, int ds, const int *sx_lut, const int *sy_lut,
+                               const uint8_t *crop_mask, int h, int w, int x1, int y1, void *hip_stream);
 gs_status gs_overlay_classmap(const uint8_t *region_bgr, const uint8_t *class_map, int h, int w,
                               const uint8_t *palette_rgb /*[n_colours*3] device*/, int n_colours, float wa, float wb,
                               uint8_t *out_bgr, void *hip_stream);
@@ -138,6 +145,15 @@ gs_status gs_espnet_ensemble_forward(gs_espnet *const *models, int n_models, con
  * dims receives {C,H,W}.  cap counts floats. */
 gs_status gs_espnet_read_stage(gs_espnet *h, const char *stage, int image, float *dst, size_t cap,
                                int dims[3]);
+
+/* Debug/test hook: run ONE block of the trunk on a caller-supplied input (host, contiguous CHW fp32) with the
+ * handle's weights and return its output (host, CHW fp32): the reference's single-module known-answer tests
+ * (DilatedParllelResidualBlockB / DownSamplerB called alone, Model.py:187-214,144-160).
+ *   kind 0: ESP block `index` of level `level` (2 or 3): in [64|128, h, w] -> out [64|128, h, w]
+ *   kind 1: the level's DownSamplerB (level2_0 / level3_0): in [19|131, h, w] -> out [64|128, h/2, w/2]
+ * h, w: input size (any size >= 1 for kind 0; even for kind 1).  Runs the plain (unfused) kernels of the block. */
+gs_status gs_espnet_block_forward(gs_espnet *h, int kind, int level, int index, const float *in, int height, int width,
+                                  float *out);
 
 /* Per-kernel timing with HIP events recorded on the launch stream.  While enabled every kernel of
  * gs_espnet_forward is bracketed by an event pair; gs_espnet_profile_read synchronises and

@@ -245,6 +245,105 @@ def test_driver_end_to_end(torch_mod, tmp_path):
     assert (out / "PAS-001" / "xmin0_ymin0_xmax128_ymax64_overlay.jpg").exists()
 
 
+def test_driver_loads_pth_and_scores_at_network_resolution(torch_mod, tmp_path):
+    """the reference's weight format and scoring: `torch.save(state_dict)` -> `--weights x.pth`
+    (VisualizeResults_iou.py:272,279), labels given, one crop NOT network-sized: the confusion matrix is built from
+    img_out.max(1)[1] at network resolution against the nearest-resized label (:195-203), not from the map that went
+    to crop size and back"""
+    from PIL import Image
+    from glomeruli_segmentation_amd import segment
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    from oracle import espnet_oracle as orc
+    from oracle import image_oracle as io
+    torch = torch_mod
+    sd = load_weights(1)
+    pth = tmp_path / "espnet_fold1.pth"
+    from collections import OrderedDict
+    torch.save(OrderedDict((k, torch.from_numpy(v)) for k, v in sd.items()), pth)
+    d = tmp_path / "org_image" / "PAS-003"
+    lab = tmp_path / "label" / "PAS-003"
+    d.mkdir(parents=True)
+    lab.mkdir(parents=True)
+    H, W = 64, 128
+    mean, std = FOLD_MEAN_STD[1]
+    crops = {"xmin0_ymin0_xmax16_ymax8.PNG": synth_tile(21, H, W, blobs=4), "xmin3_ymin3_xmax30_ymax20.PNG": synth_tile(22, 96, 192, blobs=4),
+             "xmin5_ymin5_xmax20_ymax12.PNG": synth_tile(23, 44, 100, blobs=4)}
+    rng = np.random.default_rng(3)
+    labels = {}
+    for name, c in crops.items():
+        Image.fromarray(c[:, :, ::-1]).save(d / name)
+        labels[name] = rng.integers(0, 5, c.shape[:2]).astype(np.uint8)
+        Image.fromarray(labels[name]).save(lab / name)
+    out = tmp_path / "results"
+    rc = segment.main(["--rgb_data_dir", str(tmp_path / "org_image"), "--label_data_dir", str(tmp_path / "label"), "--savedir", str(out),
+                       "--weights", str(pth), "--gpu_id", "0", "--inWidth", str(W), "--inHeight", str(H),
+                       "--mean", *[str(v) for v in mean], "--std", *[str(v) for v in std]])
+    assert rc == 0
+    # expected confusion through the oracle: normalise -> cv2-rule resize -> forward -> argmax at network resolution
+    total = np.zeros((5, 5), dtype=np.int64)
+    for name in sorted(crops):
+        x = io.normalise_then_resize(crops[name], mean, std, W, H)
+        net_map = orc.argmax(orc.espnet_forward(x, sd))
+        lab_r = io.resize_nearest(labels[name], W, H)
+        total += segment.confusion(net_map.ravel(), lab_r.ravel(), 5)
+    o, pa, pi, m = segment.metric_right(total)
+    txt = open(out / "overall_accuracy.txt").read()
+    got_acc = float(txt.split("overall_acc:")[1].split(",")[0])
+    got_miou = float(txt.split("mIOU:")[1])
+    # (a handful of razor-edge pixels may flip between the HIP path and the oracle: 3 x 8192 pixels scored)
+    assert abs(got_acc - o) <= 5e-4 and abs(got_miou - m) <= 5e-4, (got_acc, o, got_miou, m)
+    rows = open(out / "summary_accuracy.csv").read().strip().splitlines()
+    assert len(rows) == 4
+
+
+def test_block_known_answers_on_the_hip_path(torch_mod, engine1):
+    """the reference's single-module known-answer tests (ragged sizes, d=16 zero padding fully exercised)
+    through the C ABI's block hook -- the plain (unfused) kernels on 24x40 / 20x72 maps"""
+    z = load_golden("blocks_fold1.npz")
+    cases = [("esp3", 0, 3, 3), ("esp2", 0, 2, 1), ("down3", 1, 3, 0), ("down2", 1, 2, 0)]
+    for tag, kind, level, index in cases:
+        got = engine1.block_forward(kind, level, index, z[tag + "_in"])
+        ref = z[tag + "_out"]
+        assert got.shape == ref.shape, tag
+        err = float(np.abs(got - ref).max())
+        assert err <= 2e-4 * max(1.0, float(np.abs(ref).max())), (tag, err)
+
+
+def test_environment_cannot_change_results(torch_mod, sd1, monkeypatch):
+    """the diagnostic switches of round 1 are compiled out: with them set the product returns the same masks"""
+    from glomeruli_segmentation_amd.engine import EspnetEngine
+    from glomeruli_segmentation_amd.synth import synth_tile
+    tile = synth_tile(42, 64, 128, blobs=4)
+    eng = EspnetEngine(sd1)
+    ref, _, _ = _segment(torch_mod, eng, tile, want_logits=False)
+    eng.close()
+    for k, v in (("GS_VARIANT", "101"), ("GS_PRIO", "3"), ("GS_STAGGER", "8"), ("GS_NO_VEC", "1")):
+        monkeypatch.setenv(k, v)
+    eng = EspnetEngine(sd1)
+    got, _, _ = _segment(torch_mod, eng, tile, want_logits=False)
+    eng.close()
+    assert np.array_equal(got, ref)
+
+
+def test_bench_two_ranks_on_one_gpu(torch_mod):
+    """`bench.py --gpus 2` with the one-GPU rehearsal knobs (both ranks on device 0, gloo): spawns the ranks itself,
+    prints n_gpus 2, per-rank host pipelines included"""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(GS_BENCH_BACKEND="gloo", GS_BENCH_ONE_GPU="1")
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and len(j["per_rank_ms_per_step"]) == 2
+    assert j["parity"]["miou_vs_reference"] >= 0.999
+    assert sum(j["pixel_totals_all_ranks"]) == 2 * 2 * 32 * 512 * 1024
+    assert len(j["host_pipeline"]["per_rank_patches_per_s"]) == 2
+
+
 def test_driver_model_type_2(torch_mod, tmp_path):
     """--modelType 2: ESPNet-C logits at 1/8 scale + the reference's bilinear x8 upsampling, against the golden
     encoder output pushed through the same torch upsampling"""
@@ -362,50 +461,61 @@ def test_detector_primitives_self_consistency(torch_mod):
 
 
 def test_crop_stage_kernels(torch_mod):
-    """GPU crop stage vs the numpy restatement of cv2's sampling rules (parity with cv2 itself is
-    unpinned: cv2 is not installed; DESIGN.md)"""
+    """GPU crop stage (VisualizeResults_iou.py:107-116,129) against tests/golden/resize.npz -- outputs of
+    torch.nn.functional.interpolate, an implementation of cv2.resize's INTER_LINEAR / INTER_NEAREST sampling rules
+    this repo did not write (tests/golden/make_golden_resize.py) -- and against the oracle's restatement on more sizes"""
     torch = torch_mod
-    from glomeruli_segmentation_amd import imageops
     from glomeruli_segmentation_amd.engine import crop_preprocess, mask_resize_nearest
     from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    from oracle import image_oracle as io
+    z = load_golden("resize.npz")
+    gmean, gstd = [float(v) for v in z["mean"]], [float(v) for v in z["std"]]
+    for k, (h, w, oh, ow) in enumerate(z["cases"].tolist()):
+        got = crop_preprocess(torch.from_numpy(z["crop_%d" % k]).cuda(), gmean, gstd, oh, ow).cpu().numpy()
+        ref = z["net_%d" % k]
+        assert got.shape == ref.shape
+        # fp32: torch forms the four bilinear products in one expression, cv2 (and the kernel) in two passes
+        assert np.abs(got - ref).max() <= 2e-6, (k, float(np.abs(got - ref).max()))
+        back = mask_resize_nearest(torch.from_numpy(z["cmap_%d" % k]).cuda(), h, w).cpu().numpy()
+        assert np.array_equal(back, z["back_%d" % k]), k
     mean, std = FOLD_MEAN_STD[1]
     for (h, w, oh, ow) in [(300, 420, 512, 1024), (700, 1500, 512, 1024), (64, 128, 64, 128), (37, 91, 48, 40)]:
         crop = synth_tile(h + w, h, w, blobs=3)
-        ref = imageops.normalise_then_resize(crop, mean, std, ow, oh)
+        ref = io.normalise_then_resize(crop, mean, std, ow, oh)
         got = crop_preprocess(torch.from_numpy(crop).cuda(), mean, std, oh, ow).cpu().numpy()
         assert got.shape == ref.shape
         assert np.abs(got - ref).max() <= 2e-6, (h, w)
         m = np.random.default_rng(h).integers(0, 5, (oh, ow)).astype(np.uint8)
         back = mask_resize_nearest(torch.from_numpy(m).cuda(), h, w).cpu().numpy()
-        assert np.array_equal(back, imageops.resize_nearest(m, w, h)), (h, w)
+        assert np.array_equal(back, io.resize_nearest(m, w, h)), (h, w)
+
+
+def _random_crops(rng, W, H, n):
+    boxes, crops = [], []
+    for _ in range(n):
+        w, h = int(rng.integers(300, 1400)), int(rng.integers(300, 1400))
+        x1, y1 = int(rng.integers(0, W - w)), int(rng.integers(0, H - h))
+        boxes.append((x1, y1, x1 + w, y1 + h))
+        crops.append(rng.integers(0, 5, (h, w)).astype(np.uint8))
+    return boxes, crops
 
 
 def test_wsi_compositor(torch_mod):
-    """GPU compositor vs a numpy restatement of eval_wsi_segmentation.py:243-316,215-241 (windows of
-    2400 px composited with np.max at full resolution, INTER_NEAREST to 1/8, palette + addWeighted)"""
+    """GPU compositor vs the oracle's restatement of eval_wsi_segmentation.py:359-393 (window walk), :243-316
+    (np.max compositing), :215-241 (INTER_NEAREST to 1/8, palette + addWeighted)"""
     torch = torch_mod
     from glomeruli_segmentation_amd import imageops
     from glomeruli_segmentation_amd.composite import SlideCompositor
+    from oracle import image_oracle as io
     rng = np.random.default_rng(5)
-    W, H, win = 7200, 4800, 2400                     # multiples of the window: no edge-window quirks
-    boxes = []
-    for _ in range(25):
-        w, h = int(rng.integers(300, 1400)), int(rng.integers(300, 1400))
-        x1, y1 = int(rng.integers(0, W - w)), int(rng.integers(0, H - h))
-        boxes.append((x1, y1, x1 + w, y1 + h, rng.integers(0, 5, (h, w)).astype(np.uint8)))
-    comp = SlideCompositor(W, H, "cuda:0")
-    for x1, y1, x2, y2, m in boxes:
-        comp.paste(m, x1, y1)
-    # reference semantics in numpy
-    full = np.zeros((H, W), dtype=np.int64)
-    for x1, y1, x2, y2, m in boxes:
-        full[y1:y2, x1:x2] = np.maximum(full[y1:y2, x1:x2], m)
-    small = np.zeros((H // 8, W // 8), dtype=np.uint8)
-    for xi in range(W // win):
-        for yi in range(H // win):
-            wnd = full[yi * win:(yi + 1) * win, xi * win:(xi + 1) * win].astype(np.uint8)
-            small[yi * 300:(yi + 1) * 300, xi * 300:(xi + 1) * 300] = imageops.resize_nearest(wnd, 300, 300)
-    assert np.array_equal(comp.map.cpu().numpy(), small)
+    W, H = 7200, 4800                                # multiples of the window: both map definitions agree
+    boxes, crops = _random_crops(rng, W, H, 25)
+    small = io.reference_wsi_pred_map(crops, boxes, W, H)
+    for ref_windows in (False, True):
+        comp = SlideCompositor(W, H, "cuda:0", reference_windows=ref_windows)
+        for (x1, y1, x2, y2), m in zip(boxes, crops):
+            comp.paste(m, x1, y1)
+        assert np.array_equal(comp.map.cpu().numpy(), small), ref_windows
     slide = rng.integers(0, 256, (H // 8, W // 8, 3)).astype(np.uint8)
     blended = comp.overlay(slide).cpu().numpy()
     assert np.array_equal(blended, imageops.add_weighted(slide, 0.4, imageops.colourise(small), 0.6))
@@ -413,6 +523,38 @@ def test_wsi_compositor(torch_mod):
     hist = comp.confusion(gt).cpu().numpy()
     k = 5 * gt.astype(int).ravel() + small.astype(int).ravel()
     assert np.array_equal(hist, np.bincount(k, minlength=25).reshape(5, 5))
+
+
+@pytest.mark.parametrize("W,H", [(5003, 3100), (3100, 5003), (4800, 2417)])
+def test_wsi_compositor_reference_edge_windows(torch_mod, W, H):
+    """slides that are NOT multiples of the 2400-px window: with reference_windows=True the map equals the reference's
+    window walk bit for bit -- partial edge windows resampled with their own INTER_NEAREST step (:229) and, on the
+    slide taller than wide, the windows skipped by `ymax > slide_width` (:386) left empty"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.composite import SlideCompositor
+    from oracle import image_oracle as io
+    rng = np.random.default_rng(W)
+    boxes, crops = _random_crops(rng, W, H, 30)
+    # make sure the edge windows are populated
+    for (x1, y1) in [(W - 700, H - 650), (W - 333, 100), (50, H - 401)]:
+        boxes.append((x1, y1, min(x1 + 600, W), min(y1 + 600, H)))
+        crops.append(rng.integers(1, 5, (boxes[-1][3] - y1, boxes[-1][2] - x1)).astype(np.uint8))
+    ref = io.reference_wsi_pred_map(crops, boxes, W, H)
+    comp = SlideCompositor(W, H, "cuda:0", reference_windows=True)
+    for (x1, y1, x2, y2), m in zip(boxes, crops):
+        comp.paste(m, x1, y1)
+    got = comp.map.cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref)
+    if (W, H) == (3100, 5003):   # windows [2400,4800) and [4800,5003) have ymax > slide_width: never written
+        assert not ref[300:].any() and ref[:300].any()
+    # the plain definition (class at (8X, 8Y)) differs from it only inside partial / skipped windows
+    plain = SlideCompositor(W, H, "cuda:0")
+    for (x1, y1, x2, y2), m in zip(boxes, crops):
+        plain.paste(m, x1, y1)
+    fx, fy = (W // 2400) * 300, (H // 2400) * 300
+    if H <= W:
+        assert np.array_equal(plain.map.cpu().numpy()[:fy, :fx], got[:fy, :fx])
 
 
 def test_host_pipeline_pinned_in_place(torch_mod, engine1):

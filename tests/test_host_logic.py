@@ -149,21 +149,107 @@ def test_two_rank_sharding_equals_single_process(tmp_path):
     assert counts.sum() == 5 * 32 * 64
 
 
+def test_bench_spawns_one_process_per_gpu():
+    """`bench.py --gpus 2` started plainly (no torchrun) spawns two ranks before any GPU call and relays ONE JSON line
+    with n_gpus 2, per-rank times and the all-reduced totals (--dry-run: control flow only, gloo, no device work)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["config"]["global_batch"] == 64
+    assert len(j["per_rank_ms_per_step"]) == 2 and j["repeats"]["n"] == 5
+    assert j["pixel_totals_all_ranks"] == [2 * 3] * 5          # each dry step counts one pixel per class per rank
+    assert len(j["host_pipeline"]["per_rank_patches_per_s"]) == 2
+    # a world size that contradicts --gpus is refused
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+
+
+def test_product_library_has_no_diagnostic_switches():
+    """the shipped .so reads no environment: the timing / stamp variants and their knobs exist in -DGS_DIAG builds only"""
+    from glomeruli_segmentation_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"GS_VARIANT", b"GS_PRIO", b"GS_STAGGER", b"GS_NO_VEC", b"gpurun_out", b"stamps"):
+        assert name not in blob, name
+    # and in the sources every getenv sits inside an `#ifdef GS_DIAG` region
+    csrc = os.path.join(REPO, "glomeruli_segmentation_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hip", ".h", ".cpp")):
+            continue
+        stack = []
+        for line in open(os.path.join(csrc, fn)):
+            t = line.strip()
+            if t.startswith(("#ifdef", "#ifndef", "#if ")):
+                stack.append(t)
+            elif t.startswith("#endif"):
+                stack.pop()
+            elif "getenv" in t and not t.startswith("//"):
+                assert any("GS_DIAG" in c and c.startswith(("#ifdef", "#if ")) for c in stack), (fn, t)
+
+
+def test_weight_fixture_digest(sd1):
+    """the SHA-256 over (key, fp32 bytes) of the reference state_dict, written when the goldens were made,
+    pins the weight fixture that every parity test (and pack_state_dict) starts from"""
+    import hashlib
+    for fold in range(1, 6):
+        sd = load_weights(fold)
+        h = hashlib.sha256()
+        for k, v in sd.items():
+            if v.dtype == np.float32:
+                h.update(k.encode())
+                h.update(np.ascontiguousarray(v).tobytes())
+        want = bytes(load_golden("masks_fold%d.npz" % fold)["weights_sha256"].tolist()).hex()
+        assert h.hexdigest() == want, fold
+
+
 def test_image_helpers():
     from glomeruli_segmentation_amd import imageops
     rng = np.random.default_rng(0)
-    img = rng.random((6, 10, 3)).astype(np.float32)
-    assert np.array_equal(imageops.resize_linear_f32(img, 10, 6), img)             # identity at equal size
-    up = imageops.resize_linear_f32(img, 20, 12)
-    assert up.shape == (12, 20, 3) and np.allclose(up[0, 0], img[0, 0]) and np.allclose(up[-1, -1], img[-1, -1])
-    cm = rng.integers(0, 5, (6, 10)).astype(np.uint8)
-    nn = imageops.resize_nearest(cm, 20, 12)
-    assert (nn[::2, ::2] == cm).all() and (nn[1::2, 1::2] == cm).all()
     city = imageops.relabel_city(np.arange(5, dtype=np.uint8))
-    assert city.tolist() == [7, 8, 11, 12, 13]                                     # VisualizeResults_iou.py:54-81
-    a = np.full((2, 2, 3), 100, np.uint8)
-    b = np.full((2, 2, 3), 201, np.uint8)
+    assert city.tolist() == [7, 8, 11, 12, 13]                                       # VisualizeResults_iou.py:54-81
+    a = np.full((2, 2, 3), 100, dtype=np.uint8)
+    b = np.full((2, 2, 3), 201, dtype=np.uint8)
     assert imageops.add_weighted(a, 0.4, b, 0.6)[0, 0, 0] == 161                   # round(40 + 120.6)
+    cm = rng.integers(0, 5, (6, 10)).astype(np.uint8)
+    col = imageops.colourise(cm)
+    assert col.shape == (6, 10, 3) and (col[cm == 1] == [0, 0, 255]).all()           # class 1 is red, stored BGR
+
+
+def test_image_oracle_matches_independent_resize_fixture():
+    """the oracle's restatement of cv2.resize (INTER_LINEAR on float32, INTER_NEAREST) against outputs of
+    torch.nn.functional.interpolate (tests/golden/make_golden_resize.py)"""
+    from oracle import image_oracle as io
+    z = load_golden("resize.npz")
+    mean, std = z["mean"], z["std"]
+    for k, (h, w, oh, ow) in enumerate(z["cases"].tolist()):
+        got = io.normalise_then_resize(z["crop_%d" % k], mean, std, ow, oh)
+        assert got.shape == z["net_%d" % k].shape
+        assert np.abs(got - z["net_%d" % k]).max() <= 2e-6, k
+        assert np.array_equal(io.resize_nearest(z["cmap_%d" % k], w, h), z["back_%d" % k]), k
+    img = np.random.default_rng(0).random((6, 10, 3)).astype(np.float32)
+    assert np.array_equal(io.resize_linear_f32(img, 10, 6), img)                     # identity at equal size
+
+
+def test_reference_window_luts():
+    """the compositor's sample tables against the oracle's window walk on a 1-D ramp (no GPU needed)"""
+    from glomeruli_segmentation_amd.composite import reference_window_luts
+    from oracle import image_oracle as io
+    for W, H in [(5003, 3100), (3100, 5003), (7200, 4800), (2399, 2399)]:
+        sx, sy = reference_window_luts(W, H)
+        assert sx.shape == (int(W / 8),) and sy.shape == (int(H / 8),)
+        # a "crop" covering the whole slide whose value encodes the column (mod 251) + 1
+        col = (np.arange(W) % 251 + 1).astype(np.uint8)
+        full = np.broadcast_to(col, (H, W))
+        ref = io.reference_wsi_pred_map([full], [(0, 0, W, H)], W, H)
+        exp = np.zeros_like(ref)
+        ys, xs = np.nonzero(sy >= 0)[0], np.nonzero(sx >= 0)[0]
+        exp[np.ix_(ys, xs)] = col[sx[xs]][None, :]
+        assert np.array_equal(exp, ref), (W, H)
 
 
 def test_driver_flags_match_reference():
