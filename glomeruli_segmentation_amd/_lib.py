@@ -63,6 +63,12 @@ PROTOTYPES = {
     "gs_conv2d_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P]),
     "gs_roialign": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "gs_nms": (_I, [_P, _P, _I, ctypes.c_float, ctypes.c_float, _I, _P, _P, _P]),
+    "gs_detector_create": (_I, [_P, ctypes.POINTER(LayerDesc), _I, ctypes.POINTER(_P)]),
+    "gs_detector_destroy": (None, [_P]),
+    "gs_detector_max_detections": (_I, []),
+    "gs_detector_num_proposals": (_I, []),
+    "gs_detector_set_thresholds": (_I, [_P, ctypes.c_float, ctypes.c_float, ctypes.c_float]),
+    "gs_detector_forward": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -15,8 +15,8 @@ import tempfile
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libglomseg.so")
-SOURCES = ["espnet.hip", "detect_ops.hip", "contours.cpp"]
-HEADERS = ["gs_internal.h", "conv_mfma.h", "espnet_kernels.h", os.path.join("..", "..", "include", "glomseg.h")]
+SOURCES = ["espnet.hip", "detect_ops.hip", "detector.hip", "contours.cpp"]
+HEADERS = ["gs_internal.h", "conv_mfma.h", "dec_tail.h", "espnet_kernels.h", os.path.join("..", "..", "include", "glomseg.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
          "-Wno-unused-value"] + os.environ.get("GS_EXTRA_HIPCC_FLAGS", "").split()
 

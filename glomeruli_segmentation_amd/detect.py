@@ -100,20 +100,29 @@ def csv_rows(bs, x_start, y_start, downsample, site_name, specimen_id, file_name
 
 
 def scan_slide(read_region, detector, plan, conf_threshold, site_name, specimen_id, file_name, rank=0, world=1,
-               from_image=False, now=None):
+               from_image=False, now=None, batch=1):
     """The HOT LOOP of scan_region (:270-284) for this rank's contiguous window range.
-    read_region(x_start, y_start, window_x, window_y) -> uint8 RGB [window_y, window_x, 3]."""
+    read_region(x_start, y_start, window_x, window_y) -> uint8 RGB [window_y, window_x, 3].
+    batch > 1 hands the detector that many windows per call ([B,H,W,3] in, [B,K,4] / [B,K] / [B,K] / [B] out: what
+    FrcnnDetector takes); the reference's own loop is batch 1."""
     wins = plan.origins()
     lo, hi = rank_range(len(wins), rank, world)
     rows = []
-    for i, j, xs, ys in wins[lo:hi]:
-        im = np.asarray(read_region(xs, ys, plan.window_x, plan.window_y))
-        if im.shape[-1] == 4:
-            im = im[:, :, :3]                        # drop alpha (:277-278)
-        boxes, scores, classes, num = detector(im[None])
-        bs = boxes_from_detector(boxes, scores, plan.window_x, plan.window_y, conf_threshold)
-        x0, y0 = (xs * plan.downsample, ys * plan.downsample) if from_image else (xs, ys)     # :234 vs :283
-        rows.extend(csv_rows(bs, x0, y0, plan.downsample, site_name, specimen_id, file_name, now))
+    mine = wins[lo:hi]
+    for s in range(0, len(mine), max(batch, 1)):
+        chunk = mine[s:s + max(batch, 1)]
+        ims = []
+        for i, j, xs, ys in chunk:
+            im = np.asarray(read_region(xs, ys, plan.window_x, plan.window_y))
+            if im.shape[-1] == 4:
+                im = im[:, :, :3]                        # drop alpha (:277-278)
+            ims.append(im)
+        boxes, scores, classes, num = detector(np.stack(ims))
+        boxes, scores = np.asarray(boxes), np.asarray(scores)
+        for k, (i, j, xs, ys) in enumerate(chunk):
+            bs = boxes_from_detector(boxes[k], scores[k], plan.window_x, plan.window_y, conf_threshold)
+            x0, y0 = (xs * plan.downsample, ys * plan.downsample) if from_image else (xs, ys)     # :234 vs :283
+            rows.extend(csv_rows(bs, x0, y0, plan.downsample, site_name, specimen_id, file_name, now))
     return rows
 
 

@@ -38,7 +38,7 @@ def segment_crops(engine, crops, mean, std, net_h, net_w, batch=32):
 
 def run_slide(engine, read_region, slide_w, slide_h, mpp_x, mpp_y, detector, mean, std, window_um=2000, overlap=0.1,
               conf_threshold=0.2, overlap_threshold=0.35, objective_power=40, level_downsamples=(1.0, 2.0, 4.0, 8.0),
-              net_h=512, net_w=1024, rank=0, world=1, dist=None, batch=32):
+              net_h=512, net_w=1024, rank=0, world=1, dist=None, batch=32, detector_batch=1):
     """read_region(x, y, w, h, downsample) -> uint8 RGB [h,w,3] of the slide at that downsample (level-0 origin).
     Returns dict(boxes=merged boxes, masks=this rank's crop masks, map=1/8 class map (rank 0 / all ranks when
     dist is None), counts=per-class pixel totals over all crops)."""
@@ -46,7 +46,7 @@ def run_slide(engine, read_region, slide_w, slide_h, mpp_x, mpp_y, detector, mea
     level, ds = detect.pick_level(objective_power, level_downsamples)
     plan = detect.plan_windows(slide_w, slide_h, mpp_x, mpp_y, ds, window_um, overlap)
     rows = detect.scan_slide(lambda x, y, w, h: read_region(x, y, w, h, ds), detector, plan, conf_threshold, "site", "slide",
-                             "slide.ndpi", rank=rank, world=world)
+                             "slide.ndpi", rank=rank, world=world, batch=detector_batch)
     dets = [[float(v) for v in r.strip().split(',')[5:10]] for r in rows]
     if dist is not None and world > 1:
         gathered = [None] * world

@@ -169,8 +169,8 @@ gs_status gs_espnet_profile_read(gs_espnet *h, gs_kernel_time *out, int cap, int
 
 /* ------------------------------------------------------------------ detector-side primitives
  * The detector network is an external TF1 frozen graph that is not in the reference
- * (detect_glomus_test.py:419-427), so there is no gs_detector_*; these are the device ops such a
- * graph is made of.  Parity for them is unpinned. */
+ * (detect_glomus_test.py:419-427); these are the device ops such a graph is made of (gs_detector_* below assembles
+ * them).  Parity for them is unpinned. */
 
 /* conv2d, NHWC fp32, weights [kh,kw,cin,cout] (TF layout), SAME-style explicit padding, + bias, optional ReLU. */
 gs_status gs_conv2d_nhwc(const float *in, int n, int h, int w, int cin, const float *weight, int kh, int kw,
@@ -184,6 +184,30 @@ gs_status gs_roialign(const float *feat, int n, int h, int w, int c, const float
  * keep (device int32 [max_out]) receives indices in descending score order, *n_keep the count. */
 gs_status gs_nms(const float *boxes, const float *scores, int k, float iou_threshold, float score_threshold,
                  int max_out, int *keep, int *n_keep, void *hip_stream);
+
+/* ------------------------------------------------------------------ assembled detector
+ * A two-stage (Faster R-CNN shaped) detector forward behind the tensor contract of the reference's detect_box
+ * (detect_glomus_test.py:349-352 sess.run, tensors :443-450): uint8 RGB windows in, detection_boxes /
+ * detection_scores / detection_classes / num_detections out.  The reference's own network is an external frozen graph
+ * (not in the reference), so the weights here are the caller's: `table` names backbone.c1..c6, rpn.conv, rpn.head,
+ * head.h1, head.h2, head.fc (+ ".weight" [kh,kw,cin,cout] / ".bias" [cout]); glomeruli_segmentation_amd/detector.py lists
+ * the shapes and makes seeded synthetic ones.  Parity with the reference's graph is unpinned.
+ * Graph: 2/255 x - 1 -> space-to-depth(2) -> 6 conv layers (stride 16) -> RPN 3x3 + 1x1 heads over 12 grid anchors per
+ * cell -> box decode (10,10,5,5) + clip -> top-1024 -> NMS 0.7 -> 300 proposals -> crop_and_resize 14x14 -> max-pool 2 ->
+ * box head -> softmax + decode -> NMS 0.6 -> up to 100 detections, scores descending, zero padded. */
+typedef struct gs_detector gs_detector;
+gs_status gs_detector_create(const float *blob, const gs_layer_desc *table, int n_layers, gs_detector **out);
+void gs_detector_destroy(gs_detector *h);
+int gs_detector_max_detections(void); /* D = 100 */
+int gs_detector_num_proposals(void);  /* 300 */
+gs_status gs_detector_set_thresholds(gs_detector *h, float rpn_nms_iou, float det_nms_iou, float det_score_threshold);
+/* images_rgb: device uint8 [n,height,width,3].  boxes [n,D,4] normalised [ymin,xmin,ymax,xmax], scores [n,D] descending,
+ * classes [n,D] (1.0 = glomerulus, 0 = padding), num [n]: device fp32.  dbg_*: optional device taps (NULL to skip):
+ * features [n,hf,wf,256], rpn [n,hf,wf,72] (24 class logits + 48 box deltas per cell), proposals [n,300,4] in pixels,
+ * head [n*300,6] (2 class logits + 4 box deltas). */
+gs_status gs_detector_forward(gs_detector *h, const uint8_t *images_rgb, int n, int height, int width, float *boxes, float *scores,
+                              float *classes, float *num, float *dbg_features, float *dbg_rpn, float *dbg_proposals,
+                              float *dbg_head, void *hip_stream);
 
 #ifdef __cplusplus
 }

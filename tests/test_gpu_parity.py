@@ -721,3 +721,136 @@ def test_slide_pipeline_detect_merge_crop_segment_composite(torch_mod, engine1):
     X0, Y0 = -(-b[0] // 8), -(-b[1] // 8)
     sub = alone.cpu().numpy()[(Y0 * 8 - b[1])::8, (X0 * 8 - b[0])::8]
     assert np.array_equal(m[Y0:Y0 + sub.shape[0], X0:X0 + sub.shape[1]], sub)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# assembled detector (BASELINE cfg 3).  NOT reference parity: the reference's network is an external frozen graph;
+# the GPU assembly is checked against oracle/detector_oracle.py, the same graph over torch CPU operators.
+def test_detector_small_against_oracle(torch_mod):
+    torch = torch_mod
+    from glomeruli_segmentation_amd.detector import FrcnnDetector, synthetic_weights
+    from oracle import detector_oracle as do
+    sd = synthetic_weights(0)
+    rng = np.random.default_rng(11)
+    H, W = 160, 192
+    imgs = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    imgs[1, 40:120, 50:150] = (imgs[1, 40:120, 50:150] // 4 + 180).astype(np.uint8)      # some structure
+    det = FrcnnDetector(sd)
+    out = {k: v.cpu().numpy() for k, v in det.forward_device(torch.from_numpy(imgs).cuda(), taps=True).items()}
+    ref = do.detect(imgs, sd)
+    # dense stages: fp32 matrix-core sums against torch's CPU convolution (summation order differs)
+    assert out["features"].shape == ref["features"].shape
+    assert np.abs(out["features"] - ref["features"]).max() <= 1e-4 * max(1.0, np.abs(ref["features"]).max())
+    assert np.abs(out["rpn"] - ref["rpn"]).max() <= 1e-4 * max(1.0, np.abs(ref["rpn"]).max())
+    # glue stages on the GPU's own dense outputs: selection logic must agree exactly, coordinates to float rounding
+    for i in range(2):
+        prop, nv = do.proposals_from_rpn(out["rpn"][i], H, W)
+        got_nv = int((np.abs(out["proposals"][i]).sum(1) > 0).sum())
+        assert got_nv == nv, (i, got_nv, nv)
+        assert np.abs(out["proposals"][i] - prop).max() <= 2e-3, i
+        head = do.box_head(out["features"][i], out["proposals"][i], H, W, sd)
+        got_head = out["head"][i * 300:(i + 1) * 300]
+        assert np.abs(got_head[:nv] - head[:nv]).max() <= 2e-4 * max(1.0, np.abs(head).max()), i
+        b, s, c, k = do.detections_from_head(got_head, out["proposals"][i], nv, H, W)
+        assert int(out["num"][i]) == k, (i, out["num"][i], k)
+        assert np.abs(out["scores"][i] - s).max() <= 1e-6
+        assert np.abs(out["boxes"][i] - b).max() <= 1e-5
+        assert np.array_equal(out["classes"][i], c)
+    # and end to end against the oracle run on its own intermediates (same detections unless a near-tie flips)
+    # one suppression decision at an IoU within rounding of the threshold replaces one detection and shifts the tail)
+    assert np.array_equal(out["num"].astype(int), ref["num"])
+    assert np.abs(out["scores"][:, :20] - ref["scores"][:, :20]).max() <= 1e-4
+    for i in range(2):
+        missing = [v for v in ref["scores"][i] if np.abs(out["scores"][i] - v).min() > 1e-4]
+        assert len(missing) <= 2, (i, missing)
+    det.close()
+
+
+def test_detector_cfg3_batch16_1000x1000(torch_mod):
+    """BASELINE cfg 3: sixteen 1000x1000 windows in one forward; the detect_box contract's invariants, determinism,
+    batch == single-window results, and the top-k / NMS glue against the oracle on the GPU's own RPN output"""
+    import time
+    torch = torch_mod
+    from glomeruli_segmentation_amd.detector import FrcnnDetector, synthetic_weights
+    from glomeruli_segmentation_amd.synth import synth_tile
+    from oracle import detector_oracle as do
+    sd = synthetic_weights(0)
+    det = FrcnnDetector(sd)
+    wins = np.stack([synth_tile(200 + i, 1000, 1000, blobs=8)[:, :, ::-1] for i in range(4)] * 4)
+    wins[4:] = np.roll(wins[4:], 37, axis=2)                    # sixteen distinct windows from four generated ones
+    wins[8:] = np.roll(wins[8:], 91, axis=1)
+    wins[12:] = wins[12:, ::-1]
+    wins = np.ascontiguousarray(wins)
+    x = torch.from_numpy(wins).cuda()
+    out = det.forward_device(x, taps=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        out2 = det.forward_device(x)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    print("detector cfg 3: %.2f ms per batch of 16 windows of 1000x1000 = %.0f windows/s" % (ms, 16 / ms * 1e3))
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    assert o["boxes"].shape == (16, 100, 4) and o["scores"].shape == (16, 100) and o["num"].shape == (16,)
+    assert o["features"].shape == (16, 63, 63, 256)
+    for k in ("boxes", "scores", "classes", "num"):
+        assert np.array_equal(o[k], out2[k].cpu().numpy()), k                      # deterministic
+    for i in range(16):
+        n = int(o["num"][i])
+        assert 0 < n <= 100
+        assert (np.diff(o["scores"][i][:n]) <= 0).all() and (o["scores"][i][n:] == 0).all()   # sorted desc, zero padded
+        assert (o["classes"][i][:n] == 1).all() and (o["classes"][i][n:] == 0).all()
+        b = o["boxes"][i][:n]
+        assert (b >= 0).all() and (b <= 1).all() and (b[:, 2] >= b[:, 0]).all() and (b[:, 3] >= b[:, 1]).all()
+    # one window alone gives the same detections as inside the batch
+    single = det.forward_device(x[5:6])
+    assert np.array_equal(single["scores"].cpu().numpy()[0], o["scores"][5])
+    assert np.array_equal(single["boxes"].cpu().numpy()[0], o["boxes"][5])
+    # RPN glue (objectness, top-1024, decode, clip, NMS 0.7, 300 proposals) of one window against the oracle
+    prop, nv = do.proposals_from_rpn(o["rpn"][3], 1000, 1000)
+    assert int((np.abs(o["proposals"][3]).sum(1) > 0).sum()) == nv
+    assert np.abs(o["proposals"][3] - prop).max() <= 5e-3
+    b, s, c, k = do.detections_from_head(o["head"][3 * 300:4 * 300], o["proposals"][3], nv, 1000, 1000)
+    assert int(o["num"][3]) == k and np.abs(o["scores"][3] - s).max() <= 1e-6 and np.abs(o["boxes"][3] - b).max() <= 1e-5
+    det.close()
+
+
+def test_slide_pipeline_with_the_gpu_detector(torch_mod, engine1):
+    """BASELINE cfg 4 in miniature with NO Python stand-in for the detector: sliding windows -> gs_detector_forward
+    (batches of 8 windows) -> threshold / CSV rows -> merge -> crops -> ESPNet -> compositor, all on the GPU"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd import detect, pipeline
+    from glomeruli_segmentation_amd.detector import FrcnnDetector, synthetic_weights
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    mean, std = FOLD_MEAN_STD[1]
+    SW, SH, mpp = 12000, 8000, 0.25
+    canvas = synth_tile(3, SH // 8, SW // 8, blobs=10)[:, :, ::-1].copy()
+
+    def read_region(x, y, w, h, ds):
+        ys = np.clip(((y + np.arange(h) * ds) / 8).astype(int), 0, canvas.shape[0] - 1)
+        xs = np.clip(((x + np.arange(w) * ds) / 8).astype(int), 0, canvas.shape[1] - 1)
+        return canvas[ys][:, xs]
+
+    det = FrcnnDetector(synthetic_weights(0))
+    calls = {"n": 0, "windows": 0}
+
+    def detector(ims):
+        calls["n"] += 1
+        calls["windows"] += len(ims)
+        b, s, c, n = det(ims)
+        return b[:, :3], s[:, :3], c[:, :3], np.minimum(n, 3)        # the three best boxes of a window keep the test small
+
+    plan = detect.plan_windows(SW, SH, mpp, mpp, 8.0, 2000, 0.1)
+    res = pipeline.run_slide(engine1, read_region, SW, SH, mpp, mpp, detector, mean, std, conf_threshold=0.3, detector_batch=8)
+    assert calls["windows"] == len(plan.origins()) and calls["n"] == -(-len(plan.origins()) // 8)
+    assert len(res["boxes"]) >= 1
+    assert len(res["masks"]) == len(res["boxes"])
+    total = sum(int(m.numel()) for m in res["masks"])
+    assert int(res["counts"].sum()) == total
+    # the detect leg alone, window by window, gives the rows the batched leg gave
+    rows_b = detect.scan_slide(lambda x, y, w, h: read_region(x, y, w, h, 8.0), detector, plan, 0.3, "s", "p", "f", batch=8,
+                               now=__import__("datetime").datetime(2020, 1, 1))
+    rows_1 = detect.scan_slide(lambda x, y, w, h: read_region(x, y, w, h, 8.0), detector, plan, 0.3, "s", "p", "f", batch=1,
+                               now=__import__("datetime").datetime(2020, 1, 1))
+    assert rows_b == rows_1
+    det.close()
