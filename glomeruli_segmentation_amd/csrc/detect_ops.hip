@@ -185,6 +185,108 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_tiled_kernel(const ConvNhwcAr
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv2d NHWC for few input channels (the 3-channel first layer of every detector backbone): K = kh*kw*cin is walked
+// FLATTENED, two k per MFMA step, so a 3x3x3 layer is 14 k-steps (27 -> 28) instead of nine taps of two half-empty
+// channel steps.  Same 64-pixel x 64-channel wave tile and register double-buffering as the tiled kernel; a k-step's
+// (ky, kx, c) comes from a small table in LDS, its two activation operands are scalar gathers (the whole input is a
+// few MB and lives in L2).  On 16 windows of 1000x1000x3 -> 64 channels, stride 2: 22 -> see profiles/ TFLOP/s.
+__global__ void __launch_bounds__(256) conv2d_nhwc_smallcin_kernel(const ConvNhwcArgs a)
+{
+    __shared__ int lut[512];   // k -> ky << 20 | kx << 10 | c   (K <= 512)
+    const int K = a.kh * a.kw * a.cin;
+    for (int k = threadIdx.x; k < 512; k += 256) {
+        const int tap = k / a.cin, c = k - tap * a.cin;
+        const int ky = tap / a.kw, kx = tap - ky * a.kw;
+        lut[k] = k < K ? (ky << 20 | kx << 10 | c) : -1;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int r = lane & 31, kq = lane >> 5;
+    const long long npix = (long long)a.n * a.ho * a.wo;
+    const long long pix0 = ((long long)blockIdx.x * 4 + wid) * 64;
+    const int co0 = blockIdx.y * 64;
+    if (pix0 >= npix)
+        return;
+    constexpr int OOB = 0x7ffffff0;
+    const unsigned in_bytes = (unsigned)min((long long)a.n * a.h * a.w_ * a.cin * 4, (long long)0x7fffffff);
+    const unsigned w_bytes = (unsigned)((long long)K * a.cout * 4);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, w_bytes, 0x00020000);
+    int iy0[2], ix0[2];
+    long long ibase[2];
+    bool pv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const long long pix = pix0 + t * 32 + r;
+        pv[t] = pix < npix;
+        const long long pc = pv[t] ? pix : 0;
+        ix0[t] = (int)(pc % a.wo) * a.stride - a.pad;
+        iy0[t] = (int)((pc / a.wo) % a.ho) * a.stride - a.pad;
+        ibase[t] = (pc / ((long long)a.wo * a.ho)) * a.h;
+    }
+    const bool cv[2] = {co0 + r < a.cout, co0 + 32 + r < a.cout};
+    const int nstep = (K + 1) / 2;
+    struct Ops {
+        float a[2], b[2];
+    };
+    auto fetch = [&](int s, Ops &q) {
+        const int k = 2 * s + kq;
+        const int e = lut[k];
+        const int ky = e >> 20, kx = (e >> 10) & 1023, c = e & 1023;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int iy = iy0[t] + ky, ix = ix0[t] + kx;
+            const bool ok = e >= 0 && pv[t] && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w_;
+            const long long off = (((ibase[t] + iy) * a.w_ + ix) * a.cin + c) * 4;
+            q.a[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, ok ? (int)off : OOB, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            q.b[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                   rw, (e >= 0 && cv[u]) ? (k * a.cout + co0 + 32 * u + r) * 4 : OOB, 0, 0));
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            acc[t][u] = (f32x16)(0.0f);
+    Ops cur, nxt;
+    fetch(0, cur);
+    for (int s = 0; s < nstep; ++s) {
+        if (s + 1 < nstep)
+            fetch(s + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t], cur.b[u], acc[t][u], 0, 0, 0);
+        cur = nxt;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int co = co0 + 32 * u + r;
+        if (co >= a.cout)
+            continue;
+        const float b = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const long long p = pix0 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kq;
+                if (p < npix) {
+                    float v = acc[t][u][reg] + b;
+                    if (a.relu)
+                        v = fmaxf(v, 0.0f);
+                    a.out[p * a.cout + co] = v;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // tf.image.crop_and_resize, method="bilinear", extrapolation_value=0.  One thread per
 // (box, y, x, channel); channels are innermost so loads/stores coalesce in NHWC.
 __global__ void __launch_bounds__(256)
@@ -568,6 +670,13 @@ gs_status gs_conv2d_nhwc(const float *in, int n, int h, int w, int cin, const fl
     if (cin % 8 == 0 && (long long)n * h * w * cin * 4 < 0x7fffffffLL && (long long)kh * kw * cin * cout * 4 < 0x7fffffffLL) {
         dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((cout + 63) / 64));
         hipLaunchKernelGGL(conv2d_nhwc_tiled_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
+        GS_HIP(hipGetLastError());
+        return GS_OK;
+    }
+    // few input channels: flattened-K kernel (K = kh*kw*cin up to 512, channel / tap indices below 1024)
+    if (cin < 8 && (long long)kh * kw * cin <= 512 && kh < 1024 && kw < 1024 && (long long)n * h * w * cin * 4 < 0x7fffffffLL) {
+        dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((cout + 63) / 64));
+        hipLaunchKernelGGL(conv2d_nhwc_smallcin_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
         GS_HIP(hipGetLastError());
         return GS_OK;
     }

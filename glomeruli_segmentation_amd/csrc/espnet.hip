@@ -59,11 +59,12 @@ static constexpr bool no_vec() { return false; }
 //   level 2: down-sampler 0.223 -> 0.242 ms, ESP block 0.189 -> 0.21 ms (three waves per SIMD instead of four), against
 //            0.063 ms per separate 1x1 launch: -0.084 ms per step.  On.
 //   level 3: down-sampler (no residual: the second accumulator set fits beside four pixels per lane) 0.159 -> 0.175 ms
-//            against 0.032 ms for the 1x1 launch: on.  ESP blocks: with the residual registers the second accumulator
+//            against 0.032 ms for the 1x1 launch: on.  ESP blocks: beside the residual registers the second accumulator
 //            set only fits at two pixels per lane, and that form takes 0.1995 ms = exactly branch kernel + 1x1 kernel
-//            (0.167 + 0.032): no gain, off (CFG_FUSE_L3 == 2 turns it on).
+//            (0.167 + 0.032); with the residual through a half-slot register ring (F_RES_RING) it fits at four pixels
+//            per lane (24 registers spilled) and takes 0.193-0.197 ms: -0.03 ms per step, 1 %, measured twice.  On.
 #ifndef CFG_FUSE_L3
-#define CFG_FUSE_L3 1   // 0 off, 1 down-sampler only, 2 every block
+#define CFG_FUSE_L3 2   // 0 off, 1 down-sampler only, 2 every block
 #endif
 #ifndef CFG_FUSE_L2
 #define CFG_FUSE_L2 1
@@ -428,7 +429,7 @@ struct Launcher {
         if (m->profile && st == GS_OK) {
             hipEventRecord(ev.b, s);
             m->events.push_back(ev);
-            m->prof_flops[kid] = flops_per_tile;
+            m->prof_flops[kid] += flops_per_tile;   // summed like the times: launches of one kernel name may differ (fused / plain)
         }
     }
 };
@@ -1188,13 +1189,14 @@ gs_status gs_espnet_profile_read(gs_espnet *h, gs_kernel_time *out, int cap, int
         std::snprintf(out[k].name, sizeof out[k].name, "%s", kKernelNames[i]);
         out[k].total_ms = m.prof_ms[i];
         out[k].launches = m.prof_launches[i];
-        out[k].flops_per_tile = m.prof_flops[i];
+        out[k].flops_per_tile = m.prof_flops[i] / (double)m.prof_launches[i];   // mean over the launches timed
         ++k;
     }
     *n_out = k;
     for (int i = 0; i < K_COUNT; ++i) {
         m.prof_ms[i] = 0;
         m.prof_launches[i] = 0;
+        m.prof_flops[i] = 0;
     }
     return GS_OK;
 }

@@ -47,6 +47,14 @@ def pack_state_dict(state_dict):
     return blob, table
 
 
+def _check_out(t, name, shape, dtype, device):
+    if t is None:
+        return
+    if not isinstance(t, torch.Tensor) or tuple(t.shape) != tuple(shape) or t.dtype != dtype or not t.is_contiguous() or \
+            t.device.type != torch.device(device).type or (t.is_cuda and t.device != torch.device(device)):
+        raise ValueError("%s must be a contiguous %s tensor of shape %s on %s" % (name, dtype, tuple(shape), device))
+
+
 def _stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -110,6 +118,10 @@ class EspnetEngine:
         tiles_u8 = tiles_u8.contiguous()
         n, h, w, _ = tiles_u8.shape
         dev = tiles_u8.device
+        # caller-supplied outputs are written by the kernels as plain pointers: refuse anything that is not exactly the
+        # buffer the call would have allocated itself
+        _check_out(out_mask, "out_mask", (n, h, w), torch.uint8, dev)
+        _check_out(out_hist, "out_hist", (n, self.classes), torch.int64, dev)
         mask = out_mask if out_mask is not None else torch.empty((n, h, w), dtype=torch.uint8, device=dev)
         hist = None
         if want_hist:
@@ -131,6 +143,8 @@ class EspnetEngine:
             t, h, w, _ = tiles.shape
             in_ptr = ctypes.c_void_p(tiles.data_ptr())
             pin = tiles.is_pinned()
+            _check_out(out_masks, "out_masks", (t, h, w), torch.uint8, torch.device("cpu"))
+            _check_out(out_hist, "out_hist", (t, self.classes), torch.int64, torch.device("cpu"))
             masks_t = out_masks if out_masks is not None else torch.empty((t, h, w), dtype=torch.uint8, pin_memory=pin)
             hist_t = None
             if want_hist:

@@ -389,6 +389,20 @@ def test_detector_primitives_self_consistency(torch_mod):
                                   out.data_ptr(), None))
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max() <= 1e-4
+    # few input channels (flattened-K kernel): the 3-channel first layers of detector backbones, 3x3 and 7x7, odd K;
+    # and a channel count neither kernel is specialised for (generic path)
+    for (cn, hh, ww, ci, co, kk, st, pd) in [(2, 33, 41, 3, 64, 3, 2, 1), (1, 40, 37, 3, 70, 7, 2, 3), (2, 9, 11, 1, 5, 3, 1, 1),
+                                             (1, 12, 13, 12, 20, 3, 1, 1)]:
+        x = torch.randn(cn, hh, ww, ci, generator=g)
+        w = torch.randn(kk, kk, ci, co, generator=g) * 0.2
+        bias = torch.randn(co, generator=g)
+        ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), bias, st, pd)).permute(0, 2, 3, 1)
+        xd, wd, bd = x.cuda(), w.cuda(), bias.cuda()
+        out = torch.full(ref.shape, float("nan"), device="cuda")
+        _lib.check(lib.gs_conv2d_nhwc(xd.data_ptr(), cn, hh, ww, ci, wd.data_ptr(), kk, kk, co, bd.data_ptr(), st, pd, 1,
+                                      out.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert (out.cpu() - ref).abs().max() <= 2e-4, (ci, kk)
     # the tiled kernel (cin % 8 == 0): ragged pixel and channel tiles, stride 1 and 2, with and without bias / relu
     for (cn, hh, ww, ci, co, st, relu, use_bias) in ((2, 21, 37, 16, 70, 1, 1, True), (3, 30, 19, 24, 64, 2, 0, False),
                                                     (1, 9, 300, 8, 130, 1, 1, True)):

@@ -2,7 +2,8 @@
 """Secondary measurements on one MI355X (not the headline; bench.py owns that): BASELINE configs 3-5.
 
   cfg 3  detector primitives on 16 synthetic 1000x1000x3 windows: gs_conv2d_nhwc (first backbone-style
-         layers), gs_roialign (300 boxes -> 14x14 crops), gs_nms (300 boxes)  [SURVEY 8d: report GB/s]
+         layers), gs_roialign (300 boxes -> 14x14 crops), gs_nms (300 boxes)  [SURVEY 8d: report GB/s],
+         and the assembled detector forward (gs_detector_forward) on the same sixteen windows
   cfg 4  crop stage (bilinear resize + normalise of 1098^2 crops to 1024x512), nearest resize back,
          WSI max-compositor paste
   cfg 5  5-fold ensemble (softmax mean over the five shipped folds) on a batch of 32 tiles
@@ -85,6 +86,21 @@ def main():
     t = timeit(lambda: _lib.check(lib.gs_nms(boxes.data_ptr(), sc.data_ptr(), k, ctypes.c_float(0.6), ctypes.c_float(0.0), 100,
                                              keep.data_ptr(), nk.data_ptr(), None)))
     out["cfg3_nms_300"] = {"us": round(t * 1e6, 1), "pair_ious_per_s": round(k * k / t / 1e9, 3), "unit": "G pairs/s"}
+
+    # ---- cfg 3: the assembled detector (gs_detector_forward), sixteen 1000x1000 windows per call ----------------
+    from glomeruli_segmentation_amd.detector import LAYERS, FrcnnDetector, synthetic_weights
+    det = FrcnnDetector(synthetic_weights(0))
+    wins = torch.from_numpy(np.stack([synth_tile(200 + i, 1000, 1000, blobs=8)[:, :, ::-1].copy() for i in range(4)] * 4)).to(dev)
+    t = timeit(lambda: det.forward_device(wins), reps=5, warm=2)
+    sizes = {"backbone.c1": 500 * 500, "backbone.c2": 250 * 250, "backbone.c3": 125 * 125, "backbone.c4": 125 * 125, "backbone.c5": 63 * 63,
+             "backbone.c6": 63 * 63, "rpn.conv": 63 * 63, "rpn.head": 63 * 63, "head.h1": 300 * 49, "head.h2": 300 * 16, "head.fc": 300}
+    gflop = sum(2.0 * sizes[k] * kk * kk * ci * co for k, (kk, ci, co) in LAYERS.items()) / 1e9
+    out["cfg3_detector_forward_batch16_1000x1000"] = {
+        "ms_per_batch": round(t * 1e3, 2), "windows/s": round(16 / t, 1), "GFLOP_per_window": round(gflop, 2),
+        "TFLOP/s": round(16 * gflop / t / 1e3, 1), "frac_of_fp32_mfma_peak": round(16 * gflop / t / 1e3 / 157.3, 3),
+        "note": "synthetic weights (the reference's graph is external); uint8 windows resident in HBM -> detect_box tensors"}
+    det.close()
+    del wins
 
     # ---- cfg 4: crop stage + compositor ----------------------------------------------------------
     mean, std = FOLD_MEAN_STD[1]
