@@ -49,12 +49,20 @@ using IC = std::integral_constant<int, N_>;
 template <bool B_>
 using BC = std::integral_constant<bool, B_>;
 
-template <int CLS, int P>
+// A wave always drives P = 8 MFMA column blocks (128 columns).  NRUN of them make one strip of an image (16*NRUN input
+// columns -> 16*NRUN - 2 output pixels); with NRUN < 8 the wave carries the same narrow strip of 8 / NRUN consecutive
+// images side by side, so the narrow rest of a row (512 = 4 x 126 + 8) costs 1/8 of a task per image, epilogue included.
+template <int CLS, int NRUN>
 struct DecTailGeom {
-    static constexpr int NG = 6;             // plane groups of four (24 planes)
-    static constexpr int TS = 16 * P + 4;    // LDS tile row pitch (floats); + 4: the four k-groups of a tile write hit different banks
-    static constexpr int XS = 16 * P - 2;    // output pixels per strip
+    static constexpr int P = 8;
+    static constexpr int IMGS = P / NRUN;       // images per task
+    static constexpr int NG = 6;                // plane groups of four (24 planes)
+    static constexpr int TS = 16 * P + 4;       // LDS tile row pitch (floats); + 4: the four k-groups of a tile write hit different banks
+    static constexpr int CW = 16 * NRUN;        // tile columns of one image
+    static constexpr int XS = CW - 2;           // output pixels per strip
+    static constexpr int LPI = 8 * NRUN;        // lanes per image in the epilogue (two pixels per lane)
     static_assert(CLS == 5, "row layout tx*5+o is written for five classes");
+    static_assert(NRUN == 1 || NRUN == 2 || NRUN == 4 || NRUN == 8, "column blocks per image strip");
 };
 
 // (everything is local arrays + generic lambdas with compile-time indices: kept in one function body so that the
@@ -81,11 +89,11 @@ constexpr bool kDtNoEpi = false;
 #ifndef DT_MAIN_WAVES
 #define DT_MAIN_WAVES 8
 #endif
-template <int CLS, int P, bool DBG, int WAVES>
+template <int CLS, int NRUN, bool DBG, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs a)
 {
-    using DT = DecTailGeom<CLS, P>;
-    constexpr int NG = DT::NG, TS = DT::TS, XS = DT::XS;
+    using DT = DecTailGeom<CLS, NRUN>;
+    constexpr int P = DT::P, NG = DT::NG, TS = DT::TS, XS = DT::XS, IMGS = DT::IMGS, CW = DT::CW, LPI = DT::LPI;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     if (tid < 128)
@@ -123,8 +131,10 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
     for (int task = blockIdx.x * WAVES + wid; task < a.total_tasks; task += nwaves) {
         const int col = task / a.bands;
         const int b = task - col * a.bands;
-        const int n = col / a.nstrips;
-        const int s = col - n * a.nstrips;
+        const int ig = col / a.nstrips;
+        const int s = col - ig * a.nstrips;
+        const int n0 = ig * IMGS;                 // first image of the task
+        const int nimg = min(IMGS, a.N - n0);     // (the last group may be short: its spare column blocks recompute the last image)
         // every band has exactly R = 3k+2 rows; the last one is shifted up to end at the image bottom and re-computes
         // (bit-identically re-stores) the rows it shares with its neighbour, which it must not count twice
         const int rows = a.R;
@@ -132,11 +142,18 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
         const int y0 = yb + rows <= a.H1 ? yb : a.H1 - rows;
         const int x0 = a.xbase + XS * s;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(a.in + (long long)n * a.in_sn), 0, a.in_img_bytes, 0x00020000);
+            const_cast<float *>(a.in + (long long)n0 * a.in_sn), 0, a.in_img_bytes * (unsigned)nimg, 0x00020000);
         const int sbase = (a.in_off + x0 - 1) * 4;   // column x0-1 of row 0; row -1 is the zero halo row
+        // (uniform) offset of column block p: block p % NRUN of image n0 + p / NRUN -- added to the scalar offset of a load
+        int roffp[NRUN == 8 ? 1 : P];
+        if (NRUN < 8) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                roffp[p] = min(p / NRUN, nimg - 1) * (int)a.in_img_bytes + (p % NRUN) * 64;
+        }
         const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
-            a.mask ? a.mask + (long long)n * H * W : reinterpret_cast<unsigned char *>(const_cast<float *>(a.in)), 0,
-            a.mask ? (unsigned)(H * W) : 0u, 0x00020000);
+            a.mask ? a.mask : reinterpret_cast<unsigned char *>(const_cast<float *>(a.in)), 0,
+            a.mask ? (unsigned)((long long)a.N * H * W) : 0u, 0x00020000);
         unsigned long long counts = 0;               // per-lane packed per-class counts, 12 bits each
 
         auto fetch = [&](auto g_, int i) __attribute__((always_inline)) {
@@ -145,7 +162,9 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
 #pragma unroll
             for (int p = 0; p < P; ++p)
                 bq[g][p] = kDtNoLoad ? __builtin_bit_cast(float, soff + p)
-                                     : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + p * 64, soff, 0));
+                                     : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                     rs, NRUN == 8 ? voff + p * 64 : voff,
+                                                                     NRUN == 8 ? soff : soff + roffp[NRUN == 8 ? 0 : p], 0));
         };
         // one input row: every plane group feeds the vertical taps whose output row lies inside the band
         auto row_step = [&](auto ph_, auto v0_, auto v1_, auto v2_, auto more_, int inext) __attribute__((always_inline)) {
@@ -212,11 +231,13 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // lane l owns the output pixels m = 2l, 2l+1 of the strip: out[o][m] = Z[o][m] + Z[5+o][m+1] + Z[10+o][m+2]
-            const int m0 = 2 * lane;
+            // lane l owns the output pixels m = 2q, 2q+1 (q = l % LPI) of the strip of image n0 + l / LPI:
+            // out[o][m] = Z[o][m] + Z[5+o][m+1] + Z[10+o][m+2]
+            const int gi = lane / LPI, m0 = 2 * (lane % LPI);
+            const int n = n0 + gi;
             const int x = x0 + m0;
-            const bool ok = m0 < XS && x < a.W1;   // W1 and x are even: the lane's two pixels are both inside or both outside
-            const int mc = m0 < XS ? m0 : 0;
+            const bool ok = m0 < XS && x < a.W1 && gi < nimg;   // W1 and x are even: the lane's two pixels are both inside or both outside
+            const int mc = gi * CW + (m0 < XS ? m0 : 0);
             float f[2][CLS];
 #pragma unroll
             for (int o = 0; o < CLS; ++o) {
@@ -281,7 +302,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
                 __builtin_amdgcn_sched_barrier(0);
                 if (ok) {
                     if (a.mask)   // (uniform) one 32-bit offset per lane, the row in the scalar offset
-                        __builtin_amdgcn_raw_buffer_store_b32(mbytes, rmask, 2 * x, (2 * yo + dy) * W, 2 /* nt */);
+                        __builtin_amdgcn_raw_buffer_store_b32(mbytes, rmask, n * (H * W) + 2 * x, (2 * yo + dy) * W, 2 /* nt */);
                     if (DBG && a.logits) {
 #pragma unroll
                         for (int o = 0; o < CLS; ++o)
@@ -329,29 +350,45 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
         }
         closing(IC<2>{}, t);
         if (a.hist) {
-            // per-class totals of the wave: unpack, butterfly-add over the 64 lanes, one atomic per class
+            // per-class totals of every image of the task: unpack, butterfly-add over the image's lanes, one atomic per class
+            const int gi = lane / LPI;
 #pragma unroll
             for (int k = 0; k < CLS; ++k) {
                 int c = (int)((counts >> (12 * k)) & 0xfffull);
 #pragma unroll
-                for (int sh = 32; sh >= 1; sh >>= 1)
+                for (int sh = LPI / 2; sh >= 1; sh >>= 1)
                     c += __shfl_xor(c, sh, 64);
-                if (lane == 0 && c)
-                    atomicAdd(&a.hist[(long long)n * CLS + k], (unsigned long long)c);
+                if (lane % LPI == 0 && gi < nimg && c)
+                    atomicAdd(&a.hist[(long long)(n0 + gi) * CLS + k], (unsigned long long)c);
             }
         }
     }
 }
 
-constexpr int DEC_TAIL_P = DT_MAIN_P;
-
-template <int P, int WAVES>
+template <int NRUN, int WAVES>
 static gs_status launch_dec_tail_p(DecTailArgs a, int num_cus, hipStream_t stream)
 {
-    using DT = DecTailGeom<5, P>;
-    a.total_tasks = a.N * a.nstrips * a.bands;
+    using DT = DecTailGeom<5, NRUN>;
+    // band height R = 3k+2 (the kernel's loop is whole periods of its three rolling accumulator sets): about one round of
+    // tasks over the resident waves when the batch allows it -- a task is a serial sweep, so few long tasks would leave
+    // most of the chip idle; operand re-reads are (R+2)/R
+    const int slots = num_cus * WAVES;
+    const int cols = cdiv(a.N, DT::IMGS) * a.nstrips;
+    int bands = slots / cols;
+    if (bands < 1) bands = 1;
+    int k3 = (cdiv(a.H1, bands) - 2 + 2) / 3;   // smallest k with 3k+2 >= H1/bands
+    if (k3 < 0) k3 = 0;
+    while (k3 > 0 && 3 * k3 + 2 > a.H1) --k3;   // a band never exceeds the image (H1 >= 4; k3 == 0 gives two-row bands)
+    a.k3 = k3;
+    a.R = 3 * k3 + 2;
+    a.bands = cdiv(a.H1, a.R);
+    a.total_tasks = cols * a.bands;
+    if ((long long)a.N * 4 * a.H1 * a.W1 >= (1ll << 32) || (long long)DT::IMGS * a.in_img_bytes >= (1ll << 32)) {
+        set_error("dec_tail: batch of %d tiles of %dx%d exceeds the 32-bit offsets of the mask / input descriptors", a.N, 2 * a.H1, 2 * a.W1);
+        return GS_ERR_UNSUPPORTED;
+    }
     const size_t lds_bytes = (size_t)(128 + WAVES * 16 * DT::TS) * sizeof(float);
-    auto kern = a.logits ? dec_tail_kernel<5, P, true, WAVES> : dec_tail_kernel<5, P, false, WAVES>;
+    auto kern = a.logits ? dec_tail_kernel<5, NRUN, true, WAVES> : dec_tail_kernel<5, NRUN, false, WAVES>;
     static std::mutex mu;
     static std::map<int, bool> attr_done;
     int dev = 0;
@@ -372,27 +409,15 @@ static gs_status launch_dec_tail_p(DecTailArgs a, int num_cus, hipStream_t strea
 }
 
 // Full-width strips (126 output columns, eight MFMA column blocks) in one launch; the narrow rest of the row, if any,
-// in a second one instantiated for just the column blocks it needs (its work is a few per cent of the first).
+// in a second one that packs the rest strips of 8 / NRUN images into every task.
 static inline gs_status launch_dec_tail(DecTailArgs a, int num_cus, hipStream_t stream)
 {
-    constexpr int XS = DecTailGeom<5, DEC_TAIL_P>::XS;
+    constexpr int XS = DecTailGeom<5, 8>::XS;
     const int full_strips = a.W1 / XS, rest = a.W1 - full_strips * XS;
-    // band height R = 3k+2 (the kernel's loop is whole periods of its three rolling accumulator sets): about one round of
-    // full-strip tasks over the resident waves (8 per CU) when the batch allows it; operand re-reads are (R+2)/R
-    const int slots = num_cus * DT_MAIN_WAVES;
-    const int cols = a.N * (full_strips > 0 ? full_strips : 1);
-    int bands = slots / cols;
-    if (bands < 1) bands = 1;
-    int k3 = (cdiv(a.H1, bands) - 2 + 2) / 3;   // smallest k with 3k+2 >= H1/bands
-    if (k3 < 1) k3 = 1;
-    while (k3 > 0 && 3 * k3 + 2 > a.H1) --k3;   // a band never exceeds the image (H1 >= 4; k3 == 0 gives two-row bands)
-    a.k3 = k3;
-    a.R = 3 * k3 + 2;
-    a.bands = cdiv(a.H1, a.R);
     if (full_strips > 0) {
         a.xbase = 0;
         a.nstrips = full_strips;
-        gs_status st = launch_dec_tail_p<DEC_TAIL_P, DT_MAIN_WAVES>(a, num_cus, stream);
+        gs_status st = launch_dec_tail_p<8, DT_MAIN_WAVES>(a, num_cus, stream);
         if (st != GS_OK) return st;
     }
     if (rest > 0) {
