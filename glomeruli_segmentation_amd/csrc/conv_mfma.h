@@ -220,22 +220,22 @@ constexpr ConvImage conv_image(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT
     return im;
 }
 
-// Waves per SIMD the register allocator must leave room for: the level-2 branch kernels (16x16x4, four pixels per lane)
-// live on four waves per SIMD (<= 128 VGPRs); the forms with a fused 1x1 AND a residual (or the scalar pixel mapping)
-// need ~135 and are left at three unless CFG_L2_FORCE4 is set (they then spill ~15 registers).
+// Waves per SIMD the register allocator must leave room for in the level-2 branch kernels (16x16x4, four pixels per
+// lane).  Round 1 shipped a 9-step operand ring at four waves per SIMD (<= 128 VGPRs); with the fused 1x1 those forms
+// need ~135.  Measured at batch 32 (profiles/README.md): the 27-step ring (G = 9: a whole dilation in flight, ~200-240
+// VGPRs, two waves per SIMD) runs the down-sampler in 0.239 ms against 0.246 and the fused ESP block in 0.1996 against
+// 0.204; forcing four waves onto the fused forms spills and loses 5 %.  So: no floor (1) and the deep ring.
+#ifndef CFG_L2_MINW
+#define CFG_L2_MINW 1
+#endif
+// F_RES_RING: the register ring holds 1 / CFG_RES_RING_DIV of a slot's residual values (2: 24 registers spilled in the
+// fused level-3 ESP kernel, 0.190 ms; 4: no spill but the residual latency shows, 0.192 ms)
 #ifndef CFG_RES_RING_DIV
 #define CFG_RES_RING_DIV 2
 #endif
-#ifndef CFG_L2_FORCE4
-#define CFG_L2_FORCE4 0
-#endif
 constexpr int conv_min_waves(int MT, int TAPS, int NDIL, int P, int FLAGS)
 {
-    if (!(MT == 16 && TAPS == 9 && NDIL == 5 && P == 4))
-        return 1;
-    if ((FLAGS & F_FUSE1X1) && ((FLAGS & F_RES) || !(FLAGS & F_VEC)) && !CFG_L2_FORCE4)
-        return 3;
-    return 4;
+    return (MT == 16 && TAPS == 9 && NDIL == 5 && P == 4) ? CFG_L2_MINW : 1;
 }
 
 template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int G, int FLAGS>

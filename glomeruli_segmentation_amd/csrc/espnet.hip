@@ -34,7 +34,13 @@ void set_error(const char *fmt, ...)
 #define CFG_L2_C1S       16, 8,   20,  9,   2,     1,   12,   12,   L2P, 3
 #define CFG_L2_C1        16, 8,   64,  1,   1,     1,   12,   12,   L2P, 8
 #define CFG_L2_BR        16, 8,   12,  9,   1,     5,   16,   12,   L2P, 3
-#define CFG_L2_BR_P4     16, 8,   12,  9,   1,     5,   16,   12,   4, 3   // shipped: <= 128 VGPRs, four waves per SIMD
+#ifndef L2SP
+#define L2SP 4
+#endif
+#ifndef L2SG
+#define L2SG 9
+#endif
+#define CFG_L2_BR_P4     16, 8,   12,  9,   1,     5,   16,   12,   L2SP, L2SG   // shipped (4, 9): a whole dilation's operands in flight
 #define CFG_L3_C1S       32, 8,   132, 9,   2,     1,   25,   25,   4, 6
 #define CFG_L3_C1        32, 8,   128, 1,   1,     1,   25,   25,   4, 16
 #define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 3
@@ -100,8 +106,11 @@ static gs_status launch_vec(const ConvArgs &ca, int num_cus, hipStream_t s)
 #ifndef POL_L2_DOWN
 #define POL_L2_DOWN (F_ST_NT | F_ST2_NT)
 #endif
+#ifndef CFG_L2_XFLAGS
+#define CFG_L2_XFLAGS 0   // -DGS_DIAG ablation builds: F_X_NOEPI / F_X_NOLOAD / F_X_NOLDS ORed into the level-2 ESP launches
+#endif
 #ifndef POL_L2_ESP
-#define POL_L2_ESP (F_RES_NT | F_ST_NT)
+#define POL_L2_ESP (F_RES_NT | F_ST_NT | CFG_L2_XFLAGS)
 #endif
 #ifndef POL_L2_LAST
 #define POL_L2_LAST (F_RES_NT | F_ST2_NT)
