@@ -14,6 +14,11 @@ timed region.  Under `python -m torch.distributed.run` the ranks come from the l
 started plainly with --gpus N > 1 this process -- before it makes any GPU call -- starts N children
 with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, waits for them and relays rank 0's JSON line.
 
+Two batches are in flight at a time: consecutive steps go to the engine's two LANES (two activation workspaces, each on
+its own HIP stream; include/glomseg.h).  The kernels of one batch run strictly one after the other, so what overlaps is
+the tail of one batch's kernel with the head of another's; `single_lane` in the line is the same loop with one batch
+in flight.
+
 The timed K-step loop is repeated (default 5 times, barrier + synchronize on both sides of each) and
 `value` is the median repeat; every repeat's time is in the line.  `value` is the HBM-resident rate;
 `host_pipeline` (pinned host tiles in -> pinned host masks out, every rank with its own staging
@@ -32,6 +37,7 @@ sys.path.insert(0, REPO)
 
 BATCH = 32
 NBATCH = 4                       # distinct batches the steps rotate through
+LANES = 2                        # batches in flight (engine lanes)
 H, W = 512, 1024
 FLOP_PER_TILE = 7.267e9          # conv/deconv MACs x 2, unpadded channel counts
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -176,8 +182,16 @@ class DryEngine:
     def reserve(self, *a):
         pass
 
-    def segment(self, tiles, mean, std, out_mask=None, out_hist=None):
+    lanes = LANES
+
+    def segment(self, tiles, mean, std, out_mask=None, out_hist=None, lane=None):
         out_hist.fill_(1)
+
+    def lane_stream(self, lane):
+        return None
+
+    def wait_lanes(self):
+        pass
 
     def profile(self, on):
         self.on = on
@@ -252,33 +266,48 @@ def run_rank(args):
     else:
         from glomeruli_segmentation_amd.engine import EspnetEngine
         sd = load_weights()
-        eng = EspnetEngine(sd, classes=5, p=2, q=8)
+        eng = EspnetEngine(sd, classes=5, p=2, q=8, lanes=LANES)
         eng.reserve(BATCH, H, W)
         tiles_np = make_batches(rank)
     tiles = torch.from_numpy(tiles_np).to(dev)                       # resident before any timed region
     mask = torch.zeros((NBATCH,) + tiles_np.shape[1:4], dtype=torch.uint8, device=dev)
-    hist = torch.empty((tiles_np.shape[1], 5), dtype=torch.int64, device=dev)
+    hist = torch.empty((LANES, tiles_np.shape[1], 5), dtype=torch.int64, device=dev)
+    lane_totals = torch.zeros((LANES, 5), dtype=torch.int64, device=dev)
     totals = torch.zeros(5, dtype=torch.int64, device=dev)
     counter = [0]
+    mode = {"lanes": LANES}
 
     def step():
-        b = counter[0] % NBATCH
+        i = counter[0]
         counter[0] += 1
-        eng.segment(tiles[b], mean, std, out_mask=mask[b], out_hist=hist)
-        totals.add_(hist.sum(0))
+        b = i % NBATCH
+        if mode["lanes"] == 1:
+            eng.segment(tiles[b], mean, std, out_mask=mask[b], out_hist=hist[0])
+            lane_totals[0].add_(hist[0].sum(0))
+            return
+        k = i % LANES                     # consecutive steps alternate between the lanes: two batches in flight
+        eng.segment(tiles[b], mean, std, out_mask=mask[b], out_hist=hist[k], lane=k)
+        st = eng.lane_stream(k)
+        if st is None:
+            lane_totals[k].add_(hist[k].sum(0))
+        else:
+            with torch.cuda.stream(st):
+                lane_totals[k].add_(hist[k].sum(0))
 
     for _ in range(max(args.warmup, NBATCH)):   # every batch once; also loads torch's own reduce/add code objects
         step()
     sync()
 
     def timed(steps):
-        totals.zero_()
+        lane_totals.zero_()
         if dist is not None:
             dist.barrier()
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        eng.wait_lanes()
+        torch.sum(lane_totals, 0, out=totals)
         if dist is not None:
             all_reduce(totals)             # the one exchange: slide-level per-class pixel totals
         sync()
@@ -288,6 +317,12 @@ def run_rank(args):
 
     # the reported numbers: no instrumentation in the stream; max over ranks per repeat, median over repeats
     reps_local = [timed(args.steps) for _ in range(max(args.repeats, 1))]
+    mode["lanes"] = 1                      # the same loop with one batch in flight (reported as `single_lane`)
+    timed(args.steps)
+    single_local = float(np.median([timed(args.steps) for _ in range(max(args.repeats, 1))]))
+    single = max(gather_f64(single_local))
+    mode["lanes"] = LANES
+    timed(args.steps)                      # leaves `totals` from a two-lane pass
     reps = []
     for el in reps_local:
         if dist is not None:
@@ -299,13 +334,15 @@ def run_rank(args):
     per_rank_ms = gather_f64(float(np.median(reps_local)) / args.steps * 1e3)
     pixel_totals = [int(v) for v in totals.tolist()]   # all-reduced in the last repeat
 
-    # same K steps again with a HIP event pair around every kernel on the launch stream: per-kernel
+    # same K steps again, one batch in flight, with a HIP event pair around every kernel on the launch stream: per-kernel
     # durations for the roofline line (the event packets lengthen kernel boundaries, so this pass is
     # not the one quoted as throughput; its wall time is reported beside it)
+    mode["lanes"] = 1
     eng.profile(True)
     elapsed_prof = timed(args.steps)
     prof = eng.profile_read()
     eng.profile(False)
+    mode["lanes"] = LANES
 
     # PCIe-inclusive rate (never `value`): pinned host uint8 tiles -> pinned host masks through the
     # H2D / compute / D2H pipeline of gs_espnet_segment_host, every rank with its own buffers
@@ -353,17 +390,20 @@ def run_rank(args):
                     "flop_per_launch": dom["flops_per_tile"] * BATCH,
                     "avg_launch_ms": round(avg_s * 1e3, 4),
                     "launches_timed": dom["launches"], "instrumented_ms_per_step": round(elapsed_prof / args.steps * 1e3, 3),
-                    "whole_net_frac": round(value / n * FLOP_PER_TILE / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                    "whole_net_frac": round(value / n * FLOP_PER_TILE / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                    "whole_net_frac_single_lane": round(total_tiles / single / n * FLOP_PER_TILE / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
         out = {
             "metric": "patches/sec (1024x512 RGB) ESPNet p=2 q=8 5 classes", "value": round(value, 2),
             "unit": "patches/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "dry-run (no device work)" if args.dry_run else "synthetic",
             "config": {"workload": "ESPNet p=2 q=8 encoder+decoder, batch=32 synthetic 1024x512 uint8 BGR tiles per GPU, "
-                                   "normalise+forward+argmax+counts, inputs resident in HBM, steps rotate through %d distinct batches"
-                                   % NBATCH,
+                                   "normalise+forward+argmax+counts, inputs resident in HBM, steps rotate through %d distinct batches, "
+                                   "%d batches in flight (engine lanes, one HIP stream each)" % (NBATCH, LANES),
                        "global_batch": n * BATCH, "tile": [H, W], "weights": "espnet_fold1 (tests/golden)",
                        "parallelism": "tile-range per rank x%d" % n},
+            "single_lane": {"value": round(total_tiles / single, 2), "ms_per_step": round(single / args.steps * 1e3, 3),
+                            "note": "the same K steps with one batch in flight (one workspace, one stream)"},
             "repeats": {"n": len(reps), "statistic": "median of max-over-ranks", "seconds": [round(r, 6) for r in reps]},
             "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
             "pixel_totals_all_ranks": pixel_totals,

@@ -45,6 +45,9 @@ PROTOTYPES = {
     "gs_espnet_destroy": (None, [_P]),
     "gs_espnet_reserve": (_I, [_P, _I, _I, _I]),
     "gs_espnet_forward": (_I, [_P, _P, _I, _I, _I, _I, _FP, _FP, _P, _P, _P, _P]),
+    "gs_espnet_set_lanes": (_I, [_P, _I]),
+    "gs_espnet_lanes": (_I, [_P]),
+    "gs_espnet_forward_lane": (_I, [_P, _I, _P, _I, _I, _I, _I, _FP, _FP, _P, _P, _P, _P]),
     "gs_espnet_segment_host": (_I, [_P, _P, _I, _I, _I, _FP, _FP, _I, _P, _P]),
     "gs_espnet_ensemble_forward": (_I, [ctypes.POINTER(_P), _I, _P, _I, _I, _I, _FP, _FP, _P, _P, _P]),
     "gs_espnet_read_stage": (_I, [_P, ctypes.c_char_p, _I, _P, ctypes.c_size_t, ctypes.POINTER(_I * 3)]),

@@ -184,7 +184,7 @@ struct Model {
         hipStream_t copy = nullptr;
         hipEvent_t up = nullptr, done = nullptr, down = nullptr;
         int first = -1, count = 0;
-    } sl[3];   // three slots: upload of batch i+1 and download of batch i-1 overlap the compute of batch i
+    } sl[4];   // four slots: upload of batch i+2 and download of batch i-1 overlap the compute of batches i and i+1 (two lanes)
     hipStream_t pipe_compute = nullptr;
     size_t pipe_in_bytes = 0, pipe_out_bytes = 0;
     int pipe_batch = 0;
@@ -875,8 +875,15 @@ extern "C" {
 const char *gs_last_error(void) { return g_err.c_str(); }
 int gs_abi_version(void) { return 1; }
 
+// A handle = the model (weights + lane-0 workspace) plus optional extra LANES: shallow copies of the model that share
+// the device weight blob and own a workspace of their own, so that two batches can be in flight on two HIP streams
+// (gs_espnet_forward_lane).  Consecutive kernels of one forward cannot overlap (each waits for its predecessor and the
+// big ones fill every CU), but the tail of one batch's kernel and the head of another batch's can.
 struct gs_espnet {
     Model m;
+    std::vector<std::unique_ptr<Model>> lanes;   // lane k >= 1 is lanes[k - 1]
+    hipStream_t pipe_compute2 = nullptr;         // gs_espnet_segment_host: compute stream of lane 1
+    Model &lane(int k) { return k == 0 ? m : *lanes[k - 1]; }
 };
 
 gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_layers, int classes, int p, int q,
@@ -1039,6 +1046,14 @@ void gs_espnet_destroy(gs_espnet *h)
     }
     free_pipeline(h->m);
     if (h->m.pipe_compute) hipStreamDestroy(h->m.pipe_compute);
+    if (h->pipe_compute2) hipStreamDestroy(h->pipe_compute2);
+    for (auto &l : h->lanes) {
+        for (auto &ev : l->events) {
+            hipEventDestroy(ev.a);
+            hipEventDestroy(ev.b);
+        }
+        if (l->ws) hipFree(l->ws);
+    }
     if (h->m.ws) hipFree(h->m.ws);
     if (h->m.prob) hipFree(h->m.prob);
     if (h->m.dblob) hipFree(h->m.dblob);
@@ -1058,19 +1073,62 @@ gs_status gs_espnet_reserve(gs_espnet *h, int n, int height, int width)
     GS_REQUIRE(h, "null handle");
     gs_status st = check_shape(n, height, width);
     if (st != GS_OK) return st;
-    return layout_workspace(&h->m, n, height, width);
+    for (int k = 0; k <= (int)h->lanes.size(); ++k) {
+        st = layout_workspace(&h->lane(k), n, height, width);
+        if (st != GS_OK) return st;
+    }
+    return GS_OK;
 }
+
+gs_status gs_espnet_set_lanes(gs_espnet *h, int n_lanes)
+{
+    GS_REQUIRE(h, "null handle");
+    GS_REQUIRE(n_lanes >= 1 && n_lanes <= 4, "gs_espnet_set_lanes: 1 to 4 lanes (got %d)", n_lanes);
+    GS_HIP(hipDeviceSynchronize());
+    while ((int)h->lanes.size() > n_lanes - 1) {
+        if (h->lanes.back()->ws) hipFree(h->lanes.back()->ws);
+        h->lanes.pop_back();
+    }
+    while ((int)h->lanes.size() < n_lanes - 1) {
+        std::unique_ptr<Model> l(new Model(h->m));   // same weights (shared device blob), same configuration ...
+        l->ws = nullptr;                             // ... and nothing else of the original: own workspace, no pipeline, no profile
+        l->ws_bytes = 0;
+        l->ws_n = l->ws_h = l->ws_w = 0;
+        l->prob = nullptr;
+        l->prob_bytes = 0;
+        l->stages.clear();
+        l->events.clear();
+        l->profile = false;
+        for (auto &s : l->sl)
+            s = Model::Slot();
+        l->pipe_compute = nullptr;
+        l->pipe_in_bytes = l->pipe_out_bytes = 0;
+        l->pipe_batch = 0;
+        h->lanes.push_back(std::move(l));
+    }
+    return GS_OK;
+}
+
+int gs_espnet_lanes(gs_espnet *h) { return h ? 1 + (int)h->lanes.size() : 0; }
 
 gs_status gs_espnet_forward(gs_espnet *h, const void *in, int in_format, int n, int height, int width,
                             const float mean[3], const float std[3], float *logits, uint8_t *mask,
                             unsigned long long *hist, void *hip_stream)
 {
+    return gs_espnet_forward_lane(h, 0, in, in_format, n, height, width, mean, std, logits, mask, hist, hip_stream);
+}
+
+gs_status gs_espnet_forward_lane(gs_espnet *h, int lane, const void *in, int in_format, int n, int height, int width,
+                                 const float mean[3], const float std[3], float *logits, uint8_t *mask,
+                                 unsigned long long *hist, void *hip_stream)
+{
     GS_REQUIRE(h && in, "gs_espnet_forward: null handle or input");
+    GS_REQUIRE(lane >= 0 && lane <= (int)h->lanes.size(), "lane %d does not exist (gs_espnet_set_lanes)", lane);
     gs_status st = check_shape(n, height, width);
     if (st != GS_OK) return st;
     GS_REQUIRE(in_format == GS_IN_U8_BGR_NHWC || in_format == GS_IN_F32_NCHW, "unknown input format %d", in_format);
     GS_REQUIRE(in_format != GS_IN_U8_BGR_NHWC || (mean && std), "uint8 input needs mean and std");
-    Model &m = h->m;
+    Model &m = h->lane(lane);
     if (m.encoder_only) {
         GS_REQUIRE(logits && !mask && !hist, "ESPNet-C handle: only the 1/8-scale logits output exists");
     } else {
@@ -1255,9 +1313,9 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
     gs_status st = check_shape(batch, height, width);
     if (st != GS_OK) return st;
     if (batch > n_tiles) batch = n_tiles;
-    st = layout_workspace(&h->m, batch, height, width);
-    if (st != GS_OK) return st;
     const size_t in_b = (size_t)height * width * 3, out_b = (size_t)height * width;
+    constexpr int NSLOT = 4;
+    const int nl = h->lanes.empty() ? 1 : 2;   // batches alternate between (at most) two lanes, each on its own compute stream
     // caller buffers that are already page-locked (hipHostMalloc / hipHostRegister) are DMA'd in place;
     // pageable ones are staged through the pinned slot buffers with a host memcpy
     auto is_pinned = [](const void *p) {
@@ -1283,10 +1341,11 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
     };
     if (!m.pipe_compute)
         fail(hipStreamCreateWithFlags(&m.pipe_compute, hipStreamNonBlocking), "hipStreamCreate");
-    hipStream_t compute = m.pipe_compute;
+    if (nl > 1 && !h->pipe_compute2)
+        fail(hipStreamCreateWithFlags(&h->pipe_compute2, hipStreamNonBlocking), "hipStreamCreate");
     if (m.pipe_in_bytes < in_b * batch || m.pipe_out_bytes < out_b * batch || m.pipe_batch < batch) {
         free_pipeline(m);
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < NSLOT; ++i) {
             Slot &s = sl[i];
             fail(hipHostMalloc(reinterpret_cast<void **>(&s.hin), in_b * batch, hipHostMallocDefault), "hipHostMalloc");
             fail(hipHostMalloc(reinterpret_cast<void **>(&s.hout), out_b * batch, hipHostMallocDefault), "hipHostMalloc");
@@ -1303,7 +1362,8 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         m.pipe_out_bytes = out_b * batch;
         m.pipe_batch = batch;
     }
-    sl[0].first = sl[1].first = sl[2].first = -1;
+    for (int i = 0; i < NSLOT; ++i)
+        sl[i].first = -1;
     auto drain = [&](Slot &s) {   // wait for the slot's masks and hand them to the caller
         if (s.first < 0 || rc != GS_OK)
             return;
@@ -1314,9 +1374,11 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         }
         s.first = -1;
     };
-    int slot = 0;
-    for (int first = 0; first < n_tiles && rc == GS_OK; first += batch, slot = (slot + 1) % 3) {
+    int slot = 0, bi = 0;
+    for (int first = 0; first < n_tiles && rc == GS_OK; first += batch, slot = (slot + 1) % NSLOT, ++bi) {
         Slot &s = sl[slot];
+        const int lane = bi % nl;
+        hipStream_t compute = lane == 0 ? m.pipe_compute : h->pipe_compute2;
         drain(s);   // the slot's previous batch must have left its pinned buffers
         if (rc != GS_OK) break;
         const int cnt = n_tiles - first < batch ? n_tiles - first : batch;
@@ -1328,8 +1390,8 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         if (fail(hipMemcpyAsync(s.din, src, in_b * cnt, hipMemcpyHostToDevice, s.copy), "H2D copy")) break;
         fail(hipEventRecord(s.up, s.copy), "hipEventRecord");
         fail(hipStreamWaitEvent(compute, s.up, 0), "hipStreamWaitEvent");
-        gs_status st2 = gs_espnet_forward(h, s.din, GS_IN_U8_BGR_NHWC, cnt, height, width, mean, std, nullptr, s.dout,
-                                          s.dh, compute);
+        gs_status st2 = gs_espnet_forward_lane(h, lane, s.din, GS_IN_U8_BGR_NHWC, cnt, height, width, mean, std, nullptr,
+                                               s.dout, s.dh, compute);
         if (st2 != GS_OK) { rc = st2; break; }
         fail(hipEventRecord(s.done, compute), "hipEventRecord");
         fail(hipStreamWaitEvent(s.copy, s.done, 0), "hipStreamWaitEvent");
@@ -1341,8 +1403,8 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         s.first = first;
         s.count = cnt;
     }
-    for (int k = 0; k < 3; ++k)
-        drain(sl[(slot + k) % 3]);   // oldest first
+    for (int k = 0; k < NSLOT; ++k)
+        drain(sl[(slot + k) % NSLOT]);   // oldest first
     if (rc != GS_OK)
         hipDeviceSynchronize();
     return rc;

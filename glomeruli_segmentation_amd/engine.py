@@ -62,7 +62,7 @@ def _stream_ptr(device):
 class EspnetEngine:
     """One model on one GPU.  ``encoder_only`` builds ESPNet-C (keys without the 'encoder.' prefix)."""
 
-    def __init__(self, state_dict, classes=5, p=2, q=8, encoder_only=False, device=None):
+    def __init__(self, state_dict, classes=5, p=2, q=8, encoder_only=False, device=None, lanes=1):
         if not torch.cuda.is_available():
             raise RuntimeError("EspnetEngine needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU path in this build")
@@ -76,6 +76,31 @@ class EspnetEngine:
             _lib.check(self.lib.gs_espnet_create(blob.ctypes.data_as(ctypes.c_void_p), table, len(table), classes, p,
                                                  q, 1 if encoder_only else 0, ctypes.byref(h)))
         self.handle = h
+        # lanes: extra activation workspaces (weights shared) so that several batches are in flight, each on a stream of
+        # its own -- the tail of one batch's kernels overlaps the head of another's (include/glomseg.h, "LANES")
+        self.lanes = 1
+        self._lane_streams = {}
+        if lanes != 1:
+            self.set_lanes(lanes)
+
+    def set_lanes(self, n):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gs_espnet_set_lanes(self.handle, int(n)))
+        self.lanes = int(n)
+
+    def lane_stream(self, lane):
+        """the torch stream lane `lane` runs on (created on first use)"""
+        if not 0 <= lane < self.lanes:
+            raise ValueError("lane %d of %d" % (lane, self.lanes))
+        if lane not in self._lane_streams:
+            self._lane_streams[lane] = torch.cuda.Stream(device=self.device)
+        return self._lane_streams[lane]
+
+    def wait_lanes(self):
+        """make the current stream wait for everything submitted to the lanes (their outputs are then safe to use on it)"""
+        cur = torch.cuda.current_stream(self.device)
+        for st in self._lane_streams.values():
+            cur.wait_stream(st)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -108,9 +133,12 @@ class EspnetEngine:
                                                   out.data_ptr(), None, None, _stream_ptr(x.device)))
         return out
 
-    def segment(self, tiles_u8, mean, std, want_logits=False, want_hist=True, out_mask=None, out_hist=None):
+    def segment(self, tiles_u8, mean, std, want_logits=False, want_hist=True, out_mask=None, out_hist=None, lane=None):
         """uint8 BGR [N,H,W,3] on the GPU -> (mask uint8 [N,H,W], counts int64 [N,classes], logits|None).
-        One pass of VisualizeResults_iou.py:107-128,151-155 for a batch."""
+        One pass of VisualizeResults_iou.py:107-128,151-155 for a batch.
+        lane=None: on the current stream, in workspace 0.  lane=k: in workspace k on that lane's own stream (which first
+        waits for the current stream, so inputs produced there are ready); the outputs belong to the lane's stream until
+        wait_lanes() -- submit the next batch to another lane meanwhile."""
         if tiles_u8.dtype != torch.uint8 or tiles_u8.dim() != 4 or tiles_u8.shape[3] != 3 or not tiles_u8.is_cuda:
             raise ValueError("expected a uint8 [N,H,W,3] tensor on the GPU")
         if self.encoder_only:
@@ -128,10 +156,19 @@ class EspnetEngine:
             hist = out_hist if out_hist is not None else torch.empty((n, self.classes), dtype=torch.int64, device=dev)
         logits = torch.empty((n, self.classes, h, w), dtype=torch.float32, device=dev) if want_logits else None
         with torch.cuda.device(dev):
-            _lib.check(self.lib.gs_espnet_forward(
-                self.handle, tiles_u8.data_ptr(), _lib.GS_IN_U8_BGR_NHWC, n, h, w, _lib.fptr3(mean), _lib.fptr3(std),
+            if lane is None:
+                k, sp = 0, _stream_ptr(dev)
+            else:
+                st = self.lane_stream(lane)
+                st.wait_stream(torch.cuda.current_stream(dev))
+                for t in (tiles_u8, mask, hist, logits):      # (allocator: these tensors are in use on the lane's stream)
+                    if t is not None:
+                        t.record_stream(st)
+                k, sp = lane, ctypes.c_void_p(st.cuda_stream)
+            _lib.check(self.lib.gs_espnet_forward_lane(
+                self.handle, k, tiles_u8.data_ptr(), _lib.GS_IN_U8_BGR_NHWC, n, h, w, _lib.fptr3(mean), _lib.fptr3(std),
                 logits.data_ptr() if want_logits else None, mask.data_ptr(),
-                hist.data_ptr() if want_hist else None, _stream_ptr(dev)))
+                hist.data_ptr() if want_hist else None, sp))
         return mask, hist, logits
 
     def segment_host(self, tiles, mean, std, batch=32, want_hist=True, out_masks=None, out_hist=None):

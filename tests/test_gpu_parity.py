@@ -325,6 +325,36 @@ def test_environment_cannot_change_results(torch_mod, sd1, monkeypatch):
     assert np.array_equal(got, ref)
 
 
+def test_lanes_give_the_same_masks(torch_mod, sd1):
+    """two batches in flight on two lanes (two workspaces, two streams): every lane returns what the plain call returns,
+    also when the lanes run concurrently, and the host pipeline alternating its batches between the lanes too"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.engine import EspnetEngine
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    mean, std = FOLD_MEAN_STD[1]
+    tiles_np = np.stack([synth_tile(300 + i, 128, 256, blobs=5) for i in range(12)])
+    tiles = torch.from_numpy(tiles_np).cuda()
+    eng = EspnetEngine(sd1, lanes=2)
+    ref_m, ref_h, _ = eng.segment(tiles, mean, std)
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):                       # interleaved submissions: lane 0 and lane 1 busy at the same time
+        for k in (0, 1):
+            outs.append((k, eng.segment(tiles[k * 6:(k + 1) * 6], mean, std, lane=k)))
+    eng.wait_lanes()
+    torch.cuda.synchronize()
+    for k, (m, h, _) in outs:
+        assert torch.equal(m, ref_m[k * 6:(k + 1) * 6]) and torch.equal(h, ref_h[k * 6:(k + 1) * 6])
+    hm, hh = eng.segment_host(tiles_np, mean, std, batch=3)          # four batches: lanes 0,1,0,1
+    assert np.array_equal(hm, ref_m.cpu().numpy()) and np.array_equal(hh, ref_h.cpu().numpy())
+    with pytest.raises(Exception):
+        eng.segment(tiles[:1], mean, std, lane=2)
+    eng.set_lanes(1)
+    m1, _, _ = eng.segment(tiles, mean, std)
+    assert torch.equal(m1, ref_m)
+    eng.close()
+
+
 def test_bench_two_ranks_on_one_gpu(torch_mod):
     """`bench.py --gpus 2` with the one-GPU rehearsal knobs (both ranks on device 0, gloo): spawns the ranks itself,
     prints n_gpus 2, per-rank host pipelines included"""
