@@ -181,11 +181,13 @@ struct Model {
     struct Slot {
         uint8_t *hin = nullptr, *hout = nullptr, *din = nullptr, *dout = nullptr;
         unsigned long long *hh = nullptr, *dh = nullptr;
-        hipStream_t copy = nullptr;
         hipEvent_t up = nullptr, done = nullptr, down = nullptr;
         int first = -1, count = 0;
     } sl[4];   // four slots: upload of batch i+2 and download of batch i-1 overlap the compute of batches i and i+1 (two lanes)
-    hipStream_t pipe_compute = nullptr;
+    // ONE upload stream, ONE download stream, one compute stream per lane: HIP multiplexes streams onto a few hardware
+    // queues, and with a copy stream per slot a download landed on the compute stream's queue every other batch and held
+    // the next batch's first kernel back by its 0.35 ms
+    hipStream_t pipe_compute = nullptr, pipe_h2d = nullptr, pipe_d2h = nullptr;
     size_t pipe_in_bytes = 0, pipe_out_bytes = 0;
     int pipe_batch = 0;
 
@@ -855,7 +857,6 @@ static void free_pipeline(Model &m)
         if (s.din) hipFree(s.din);
         if (s.dout) hipFree(s.dout);
         if (s.dh) hipFree(s.dh);
-        if (s.copy) hipStreamDestroy(s.copy);
         if (s.up) hipEventDestroy(s.up);
         if (s.done) hipEventDestroy(s.done);
         if (s.down) hipEventDestroy(s.down);
@@ -1046,6 +1047,8 @@ void gs_espnet_destroy(gs_espnet *h)
     }
     free_pipeline(h->m);
     if (h->m.pipe_compute) hipStreamDestroy(h->m.pipe_compute);
+    if (h->m.pipe_h2d) hipStreamDestroy(h->m.pipe_h2d);
+    if (h->m.pipe_d2h) hipStreamDestroy(h->m.pipe_d2h);
     if (h->pipe_compute2) hipStreamDestroy(h->pipe_compute2);
     for (auto &l : h->lanes) {
         for (auto &ev : l->events) {
@@ -1101,7 +1104,7 @@ gs_status gs_espnet_set_lanes(gs_espnet *h, int n_lanes)
         l->profile = false;
         for (auto &s : l->sl)
             s = Model::Slot();
-        l->pipe_compute = nullptr;
+        l->pipe_compute = l->pipe_h2d = l->pipe_d2h = nullptr;
         l->pipe_in_bytes = l->pipe_out_bytes = 0;
         l->pipe_batch = 0;
         h->lanes.push_back(std::move(l));
@@ -1343,6 +1346,10 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         fail(hipStreamCreateWithFlags(&m.pipe_compute, hipStreamNonBlocking), "hipStreamCreate");
     if (nl > 1 && !h->pipe_compute2)
         fail(hipStreamCreateWithFlags(&h->pipe_compute2, hipStreamNonBlocking), "hipStreamCreate");
+    if (!m.pipe_h2d)
+        fail(hipStreamCreateWithFlags(&m.pipe_h2d, hipStreamNonBlocking), "hipStreamCreate");
+    if (!m.pipe_d2h)
+        fail(hipStreamCreateWithFlags(&m.pipe_d2h, hipStreamNonBlocking), "hipStreamCreate");
     if (m.pipe_in_bytes < in_b * batch || m.pipe_out_bytes < out_b * batch || m.pipe_batch < batch) {
         free_pipeline(m);
         for (int i = 0; i < NSLOT; ++i) {
@@ -1353,7 +1360,6 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
             fail(hipMalloc(reinterpret_cast<void **>(&s.din), in_b * batch), "hipMalloc");
             fail(hipMalloc(reinterpret_cast<void **>(&s.dout), out_b * batch), "hipMalloc");
             fail(hipMalloc(reinterpret_cast<void **>(&s.dh), sizeof(unsigned long long) * 5 * batch), "hipMalloc");
-            fail(hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking), "hipStreamCreate");
             fail(hipEventCreateWithFlags(&s.up, hipEventDisableTiming), "hipEventCreate");
             fail(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
             fail(hipEventCreateWithFlags(&s.down, hipEventDisableTiming), "hipEventCreate");
@@ -1387,19 +1393,20 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
             std::memcpy(s.hin, src, in_b * cnt);
             src = s.hin;
         }
-        if (fail(hipMemcpyAsync(s.din, src, in_b * cnt, hipMemcpyHostToDevice, s.copy), "H2D copy")) break;
-        fail(hipEventRecord(s.up, s.copy), "hipEventRecord");
+        // (the slot's device buffers: its previous batch was drained above, i.e. computed and downloaded)
+        if (fail(hipMemcpyAsync(s.din, src, in_b * cnt, hipMemcpyHostToDevice, m.pipe_h2d), "H2D copy")) break;
+        fail(hipEventRecord(s.up, m.pipe_h2d), "hipEventRecord");
         fail(hipStreamWaitEvent(compute, s.up, 0), "hipStreamWaitEvent");
         gs_status st2 = gs_espnet_forward_lane(h, lane, s.din, GS_IN_U8_BGR_NHWC, cnt, height, width, mean, std, nullptr,
                                                s.dout, s.dh, compute);
         if (st2 != GS_OK) { rc = st2; break; }
         fail(hipEventRecord(s.done, compute), "hipEventRecord");
-        fail(hipStreamWaitEvent(s.copy, s.done, 0), "hipStreamWaitEvent");
-        fail(hipMemcpyAsync(out_pinned ? masks + (size_t)first * out_b : s.hout, s.dout, out_b * cnt, hipMemcpyDeviceToHost, s.copy), "D2H copy");
+        fail(hipStreamWaitEvent(m.pipe_d2h, s.done, 0), "hipStreamWaitEvent");
+        fail(hipMemcpyAsync(out_pinned ? masks + (size_t)first * out_b : s.hout, s.dout, out_b * cnt, hipMemcpyDeviceToHost, m.pipe_d2h), "D2H copy");
         if (hist || !out_pinned)
             fail(hipMemcpyAsync(out_pinned ? reinterpret_cast<void *>(hist + (size_t)first * 5) : reinterpret_cast<void *>(s.hh), s.dh,
-                                sizeof(unsigned long long) * 5 * cnt, hipMemcpyDeviceToHost, s.copy), "D2H copy");
-        fail(hipEventRecord(s.down, s.copy), "hipEventRecord");
+                                sizeof(unsigned long long) * 5 * cnt, hipMemcpyDeviceToHost, m.pipe_d2h), "D2H copy");
+        fail(hipEventRecord(s.down, m.pipe_d2h), "hipEventRecord");
         s.first = first;
         s.count = cnt;
     }
