@@ -50,6 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=5, help="times the K-step loop is timed (median reported)")
+    ap.add_argument("--lanes", type=int, default=LANES, help="batches in flight (1 = one workspace, one stream: what the "
+                                                             "rocprofv3 passes of tools/profile_round.sh use, so that "
+                                                             "kernel durations are not stretched by a co-running batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-pipeline", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
@@ -182,8 +185,6 @@ class DryEngine:
     def reserve(self, *a):
         pass
 
-    lanes = LANES
-
     def segment(self, tiles, mean, std, out_mask=None, out_hist=None, lane=None):
         out_hist.fill_(1)
 
@@ -206,6 +207,8 @@ class DryEngine:
 def run_rank(args):
     import numpy as np
     import torch
+    global LANES
+    LANES = max(1, min(int(args.lanes), 4))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
