@@ -898,3 +898,24 @@ def test_slide_pipeline_with_the_gpu_detector(torch_mod, engine1):
                                now=__import__("datetime").datetime(2020, 1, 1))
     assert rows_b == rows_1
     det.close()
+
+
+def test_slide_bench_shards_consistently(torch_mod):
+    """tools/bench_slide.py (BASELINE cfg 4: detect -> merge -> crop -> segment -> composite over one synthetic slide):
+    two ranks (on this one GPU, gloo rehearsal knobs) give the pixel totals and the composited map of one rank"""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(REPO, "tools", "bench_slide.py"), "--size", "16000"]
+    one = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run(cmd + ["--gpus", "2"], env=dict(env, GS_BENCH_BACKEND="gloo", GS_BENCH_ONE_GPU="1"), capture_output=True,
+                         text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    b = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert a["crops"] == b["crops"] > 0 and a["windows"] == b["windows"] > 0
+    assert a["pixel_totals"] == b["pixel_totals"] and a["map_nonzero"] == b["map_nonzero"] > 0
+    assert sum(a["pixel_totals"]) > 0

@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""BASELINE config 4 at its stated size: detect -> merge -> crop -> segment -> composite over ONE synthetic
+40 000 x 40 000 whole-slide image (mpp 0.2277, objective 40x, detector windows of 2000 um with 0.1 overlap read
+at downsample 8, "detections" = the 28 annotated boxes of the reference's example slide repeated on a grid), tile-sharded
+over the ranks (one process per GPU, `--gpus N` spawns them like bench.py; no data-path collective, one all-reduce of
+the 1/8 map and the per-class totals at the end).  Secondary measurement -- bench.py owns the headline.
+
+    python tools/bench_slide.py [--gpus N] [--size 40000]       ->  one JSON line (rank 0)
+
+The canvas is never materialised: `SynthSlide.read_region` evaluates a seeded field (stain-coloured base + Gaussian
+blobs at the box centres + hashed pixel noise) on the sampling grid that is asked for, like OpenSlide would decode a region.
+The detector runs for real (gs_detector_forward, synthetic weights -- the reference's graph is external) on every
+window, and its boxes go through the reference's thresholding / CSV arithmetic; since untrained weights put boxes
+anywhere, the boxes that are cropped and segmented are the example-slide pattern, as SURVEY 8d prescribes.
+"""
+import argparse
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+class SynthSlide:
+    def __init__(self, width, height, boxes, seed=0):
+        import numpy as np
+        self.w, self.h = width, height
+        rng = np.random.default_rng(seed)
+        b = np.asarray(boxes, dtype=np.float64)
+        self.cx, self.cy = (b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2
+        self.sig = np.maximum(b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]) / 4.0
+        self.col = rng.standard_normal((len(b), 3)) * np.array([28.0, 43.0, 20.0]) * 1.5      # RGB offsets
+
+    def read_region(self, x, y, w, h, ds):
+        """uint8 RGB [h,w,3] of the level-0 rectangle starting at (x,y), sampled every `ds` pixels"""
+        import numpy as np
+        xs = x + np.arange(w, dtype=np.float64) * ds
+        ys = y + np.arange(h, dtype=np.float64) * ds
+        img = np.empty((h, w, 3), dtype=np.float32)
+        img[:] = np.array([199.0, 170.0, 204.0], dtype=np.float32)
+        x1, y1 = xs[-1], ys[-1]
+        near = (self.cx + 4 * self.sig > x) & (self.cx - 4 * self.sig < x1) & (self.cy + 4 * self.sig > y) & (self.cy - 4 * self.sig < y1)
+        for k in np.nonzero(near)[0]:
+            gx = np.exp(-((xs - self.cx[k]) ** 2) / (2 * self.sig[k] ** 2)).astype(np.float32)
+            gy = np.exp(-((ys - self.cy[k]) ** 2) / (2 * self.sig[k] ** 2)).astype(np.float32)
+            img += (gy[:, None] * gx[None, :])[:, :, None] * self.col[k].astype(np.float32)
+        # hashed noise: a function of the level-0 coordinate only, so overlapping reads agree
+        hx = (xs.astype(np.int64) * 73856093) & 0xFFFF
+        hy = (ys.astype(np.int64) * 19349663) & 0xFFFF
+        n = ((hy[:, None] ^ hx[None, :]) * 2654435761 >> 7) & 0x1F
+        img += (n.astype(np.float32) - 15.5)[:, :, None] * 0.6
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def grid_boxes(size, example):
+    """the example slide's 28 annotated boxes (a 53 248 x 23 040 level-0 field): positions scaled to the canvas width,
+    sizes kept, the band repeated down the canvas"""
+    import numpy as np
+    ex = np.asarray(example, dtype=np.int64)
+    fw, fh = 53248, 23040
+    sc = size / float(fw)
+    band = int(fh * sc)
+    out = []
+    for oy in range(0, size, band):
+        for x1, y1, x2, y2 in ex:
+            cx, cy = (x1 + x2) / 2 * sc, (y1 + y2) / 2 * sc + oy
+            w, h = x2 - x1, y2 - y1
+            bx1, by1 = int(cx - w / 2) // 8 * 8, int(cy - h / 2) // 8 * 8
+            if bx1 >= 0 and by1 >= 0 and bx1 + w < size and by1 + h < size:
+                out.append([bx1, by1, bx1 + int(w), by1 + int(h)])
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn(args):
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", str(free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["WORLD_SIZE"] = str(args.gpus)
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL) for r in range(args.gpus)]
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    return 1 if any(rcs) else 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--size", type=int, default=40000)
+    ap.add_argument("--detector-batch", type=int, default=16)
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn(args)
+
+    import numpy as np
+    import torch
+    from glomeruli_segmentation_amd import detect, merge
+    from glomeruli_segmentation_amd.composite import SlideCompositor
+    from glomeruli_segmentation_amd.detector import FrcnnDetector, synthetic_weights
+    from glomeruli_segmentation_amd.engine import EspnetEngine
+    from glomeruli_segmentation_amd.pipeline import segment_crops
+    from glomeruli_segmentation_amd.shard import rank_range
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = 0 if os.environ.get("GS_BENCH_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    def all_reduce(t, op=None):
+        kw = {} if op is None else {"op": op}
+        if backend == "nccl" or not t.is_cuda:
+            dist.all_reduce(t, **kw)
+        else:
+            tc = t.cpu()
+            dist.all_reduce(tc, **kw)
+            t.copy_(tc)
+
+    S, mpp = args.size, 0.2277
+    example = np.load(os.path.join(REPO, "tests", "golden", "merge.npz"))["example_boxes"]
+    boxes_all = grid_boxes(S, example)
+    slide = SynthSlide(S, S, boxes_all)
+    mean, std = FOLD_MEAN_STD[1]
+    z = np.load(os.path.join(REPO, "tests", "golden", "weights_fold1.npz"))
+    eng = EspnetEngine({k: z[k] for k in z.files})
+    det = FrcnnDetector(synthetic_weights(0))
+    t_start = time.perf_counter()
+
+    # ---- detect leg: this rank's windows (detect_glomus_test.py:270-284), sixteen per detector call
+    level, ds = detect.pick_level(40, (1.0, 2.0, 4.0, 8.0))
+    plan = detect.plan_windows(S, S, mpp, mpp, ds, 2000, 0.1)
+    wins = plan.origins()
+    lo, hi = rank_range(len(wins), rank, world)
+    t0 = time.perf_counter()
+    regions = [slide.read_region(xs, ys, plan.window_x, plan.window_y, ds) for (_, _, xs, ys) in wins[lo:hi]]
+    t_read_w = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rows = []
+    it = iter(regions)
+
+    def reader(xs, ys, w, h):
+        return next(it)
+    rows = detect.scan_slide(reader, det, plan, 0.2, "site", "slide", "slide.ndpi", rank=rank, world=world, batch=args.detector_batch)
+    torch.cuda.synchronize()
+    t_detect = time.perf_counter() - t0
+    dets = [[float(v) for v in r.strip().split(",")[5:10]] for r in rows]
+    merged_det = merge.merge_detections(dets, mpp, mpp, 0.35, 0.2) if dets else []
+
+    # ---- crop + segment + composite leg: this rank's share of the pattern boxes (make_seg_data.py:357-361 crops)
+    blo, bhi = rank_range(len(boxes_all), rank, world)
+    mine = boxes_all[blo:bhi]
+    t0 = time.perf_counter()
+    crops = [np.ascontiguousarray(slide.read_region(b[0], b[1], b[2] - b[0], b[3] - b[1], 1.0)[:, :, ::-1]) for b in mine]
+    t_read_c = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    masks = segment_crops(eng, crops, mean, std, 512, 1024, 32)
+    comp = SlideCompositor(S, S, dev)
+    counts = torch.zeros(5, dtype=torch.int64, device=dev)
+    for b, m in zip(mine, masks):
+        comp.paste(m, b[0], b[1])
+        counts += torch.bincount(m.flatten().long(), minlength=5)[:5]
+    if dist is not None:
+        all_reduce(counts)
+        all_reduce(comp.map, op=dist.ReduceOp.MAX)        # the one exchange: max-composite is associative
+    torch.cuda.synchronize()
+    t_seg = time.perf_counter() - t0
+    t_total = time.perf_counter() - t_start
+
+    def mx(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    t_detect_m, t_seg_m, t_read_m, t_total_m = mx(t_detect), mx(t_seg), mx(t_read_w + t_read_c), mx(t_total)
+    if rank == 0:
+        print(json.dumps({
+            "config": "cfg 4: detect -> merge -> crop -> segment -> composite, one synthetic %d x %d slide, %d rank(s)" % (S, S, world),
+            "windows": len(wins), "window_px": [plan.window_y, plan.window_x], "crops": len(boxes_all),
+            "detect_leg_s": round(t_detect_m, 3), "windows_per_s": round(len(wins) / t_detect_m, 1),
+            "segment_composite_leg_s": round(t_seg_m, 3), "crops_per_s": round(len(boxes_all) / t_seg_m, 1),
+            "gpu_legs_s": round(t_detect_m + t_seg_m, 3),
+            "synthetic_region_generation_s": round(t_read_m, 3),
+            "slide_total_s": round(t_total_m, 3),
+            "detector_rows_rank0": len(rows), "detector_merged_rank0": len(merged_det),
+            "pixel_totals": [int(v) for v in counts.tolist()], "map_nonzero": int((comp.map > 0).sum().item()),
+            "note": "max over ranks per leg; the region generator stands in for OpenSlide and is CPU numpy",
+        }))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
