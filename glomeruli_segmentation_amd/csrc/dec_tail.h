@@ -83,9 +83,6 @@ constexpr bool kDtNoEpi = false;
 #ifndef DT_PRIO
 #define DT_PRIO 1      // second half of the workgroup's waves at s_setprio 1 (see below)
 #endif
-#ifndef DT_MAIN_P
-#define DT_MAIN_P 8    // MFMA column blocks per strip of the main launch
-#endif
 #ifndef DT_MAIN_WAVES
 #define DT_MAIN_WAVES 8
 #endif

@@ -594,7 +594,9 @@ gs_status gs_detector_forward(gs_detector *h, const uint8_t *images_rgb, int n, 
     const int h8 = conv_out(h4, d.c3), w8 = conv_out(w4, d.c3);
     const int hf = conv_out(h8, d.c5), wf = conv_out(w8, d.c5);
     const long long cells = (long long)hf * wf, anchors = cells * DET_A;
-    GS_REQUIRE((long long)n * h2 * w2 * 64 * 4 < (1ll << 32) * 2 && anchors < (1 << 24), "gs_detector_forward: batch too large");
+    // (the tiled convolution addresses a whole input tensor with 32-bit byte offsets: beyond 2 GiB gs_conv2d_nhwc falls back
+    // to its untiled kernel, still correct; the limits here are the glue kernels' own 32-bit indices)
+    GS_REQUIRE(anchors < (1 << 24) && (long long)n * DET_PRE_NMS < (1 << 30), "gs_detector_forward: batch too large (n=%d)", n);
     const int P = DET_PROPOSALS, K1 = DET_PRE_NMS, K2 = 512;
     // workspace carve-up (floats unless noted)
     struct Piece { size_t off, bytes; };
