@@ -640,6 +640,9 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                     a.stamp[wg * 64 + 34 + di * 4 + r] = __builtin_amdgcn_s_memrealtime();
                 const int ch0 = M::row(r, 0);   // channel held by k-group 0; group kq holds ch0 + kq*KSTR
                 const bool live = ch0 + kq * KSTR < nout;
+                // (read at the top of the register's step, not inside the uniform branch around its MFMAs: the LDS
+                // latency then runs under the BN / PReLU arithmetic instead of in front of the matrix instructions)
+                const float a2 = FUSE ? tab[(di * M::NACC + r) * 64 + lane] : 0.0f;
                 const int so = (cb + ch0) * a.out_sc * 4 + sout;
                 const int so2 = DUAL ? (a.out2_coff + cb + ch0) * a.out2_sc * 4 + sout2 : 0;
                 float scale = 1.0f, shift = 0.0f, alpha = 1.0f, scale2 = 1.0f, shift2 = 0.0f, alpha2 = 1.0f;
@@ -689,7 +692,6 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                     buf_store_vec<P, SAUX2>(rout2, live ? vo2[0] + so2 : OOB, o2);
                 if (FUSE && ch0 < nout) {   // (uniform) registers whose two channels are both beyond the slot hold nothing
                     // k = lane's k-group <-> channel cb + ch0 + kq*KSTR; the table row is zero for channels beyond the slot
-                    const float a2 = tab[(di * M::NACC + r) * 64 + lane];
 #pragma unroll
                     for (int p = 0; p < P; ++p)
                         acc2[p] = M::run(a2, o1[p], acc2[p]);
