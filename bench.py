@@ -188,9 +188,6 @@ class DryEngine:
     def segment(self, tiles, mean, std, out_mask=None, out_hist=None, lane=None):
         out_hist.fill_(1)
 
-    def lane_stream(self, lane):
-        return None
-
     def wait_lanes(self):
         pass
 
@@ -274,8 +271,9 @@ def run_rank(args):
         tiles_np = make_batches(rank)
     tiles = torch.from_numpy(tiles_np).to(dev)                       # resident before any timed region
     mask = torch.zeros((NBATCH,) + tiles_np.shape[1:4], dtype=torch.uint8, device=dev)
-    hist = torch.empty((LANES, tiles_np.shape[1], 5), dtype=torch.int64, device=dev)
-    lane_totals = torch.zeros((LANES, 5), dtype=torch.int64, device=dev)
+    # per-class counts of every step of a timed loop (each step has its own [batch, 5] slice); summed once at its end
+    nslots = max(args.steps, args.warmup, NBATCH)
+    hist = torch.zeros((nslots, tiles_np.shape[1], 5), dtype=torch.int64, device=dev)
     totals = torch.zeros(5, dtype=torch.int64, device=dev)
     counter = [0]
     mode = {"lanes": LANES}
@@ -284,25 +282,19 @@ def run_rank(args):
         i = counter[0]
         counter[0] += 1
         b = i % NBATCH
+        h = hist[i % nslots]
         if mode["lanes"] == 1:
-            eng.segment(tiles[b], mean, std, out_mask=mask[b], out_hist=hist[0])
-            lane_totals[0].add_(hist[0].sum(0))
+            eng.segment(tiles[b], mean, std, out_mask=mask[b], out_hist=h)
             return
-        k = i % LANES                     # consecutive steps alternate between the lanes: two batches in flight
-        eng.segment(tiles[b], mean, std, out_mask=mask[b], out_hist=hist[k], lane=k)
-        st = eng.lane_stream(k)
-        if st is None:
-            lane_totals[k].add_(hist[k].sum(0))
-        else:
-            with torch.cuda.stream(st):
-                lane_totals[k].add_(hist[k].sum(0))
+        # consecutive steps alternate between the lanes: two batches in flight
+        eng.segment(tiles[b], mean, std, out_mask=mask[b], out_hist=h, lane=i % LANES)
 
     for _ in range(max(args.warmup, NBATCH)):   # every batch once; also loads torch's own reduce/add code objects
         step()
     sync()
 
     def timed(steps):
-        lane_totals.zero_()
+        counter[0] = 0
         if dist is not None:
             dist.barrier()
         sync()
@@ -310,7 +302,7 @@ def run_rank(args):
         for _ in range(steps):
             step()
         eng.wait_lanes()
-        torch.sum(lane_totals, 0, out=totals)
+        torch.sum(hist[:steps], (0, 1), out=totals)   # slide-level per-class pixel totals of this rank
         if dist is not None:
             all_reduce(totals)             # the one exchange: slide-level per-class pixel totals
         sync()

@@ -576,6 +576,10 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         a.N = n;
         a.H = H;
         a.W = W;
+        if (hist && !m->encoder_only) {   // zeroed by the first kernel of the forward; the last one adds into it
+            a.hist_zero = hist;
+            a.hist_count = n * CLS;
+        }
         if (in_format == GS_IN_U8_BGR_NHWC)
             hipLaunchKernelGGL(stem_kernel<true>, dim3(blocks_for((long long)n * H1 * ((W1 + STEM_PX - 1) / STEM_PX))), dim3(256), 0, s, a);
         else
@@ -787,12 +791,6 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     });
     set_stage("up_l2", m->ee, CLS);
     // ---- conv CBR(19+c,c,3) + classifier deconv + argmax + counts (Model.py:375-377, VisualizeResults_iou.py:128,151-155)
-    if (hist) {
-        if (hipMemsetAsync(hist, 0, sizeof(unsigned long long) * n * CLS, s) != hipSuccess) {
-            set_error("hipMemsetAsync(hist) failed");
-            return GS_ERR_HIP;
-        }
-    }
 #ifdef GS_DIAG
     if (m->variant == 30 || (m->variant >= 171 && m->variant <= 173)) {   // the two-kernel tail this build replaced, for A/B timing
         L.run(K_DEC_CONV, px1 * ((19 + CLS) * 9 * CLS * 2), [&] {

@@ -89,6 +89,8 @@ struct StemArgs {
     const float *b1;         // b1 folded [3][19]
     ActV a0;                 // out: output0_cat, 19 channels, (H/2 x W/2)
     ActV inp1;               // out: raw pooled input, 3 channels (feeds sample2's second pool)
+    unsigned long long *hist_zero;   // optional: per-class counters the decoder tail adds into, zeroed here (first kernel of the
+    int hist_count;                  // forward) instead of by a separate fill launch
     int N, H, W;             // INPUT size
 };
 
@@ -127,6 +129,9 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
         }
         __syncthreads();
     }
+    if (a.hist_zero && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < a.hist_count; i += 256)
+            a.hist_zero[i] = 0ull;
     const int H1 = a.H / 2, W1 = a.W / 2;
     const int W1p = (W1 + STEM_PX - 1) / STEM_PX;   // pixel pairs per row
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
