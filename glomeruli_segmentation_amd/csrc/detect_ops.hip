@@ -293,6 +293,9 @@ __global__ void __launch_bounds__(256)
 roialign_kernel(const float *feat, int n, int h, int w, int c, const float *boxes, const int *box_image, int n_boxes,
                 int crop, float *out)
 {
+    // no fused multiply-add here: a sample that lands exactly on the border of the feature map is inside or extrapolated
+    // by the last bit of in_y / in_x, and TensorFlow rounds every operation (see det_crop_pool_kernel)
+#pragma clang fp contract(off)
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)n_boxes * crop * crop * c;
     if (idx >= total)

@@ -96,6 +96,61 @@ __global__ void __launch_bounds__(256) det_maxpool_kernel(const float *in, long 
     *reinterpret_cast<float4 *>(out + p * c + cq * 4) = m;
 }
 
+// tf.image.crop_and_resize (bilinear, extrapolation 0; the arithmetic of gs_roialign) of a crop x crop grid followed by the
+// 2x2 / stride-2 max-pool, in one pass: the 14x14 crops (0.96 GB for 4800 boxes of 256 channels) are neither written nor
+// read back.  One thread per (box, pooled y, pooled x, four channels).
+__global__ void __launch_bounds__(256)
+det_crop_pool_kernel(const float *feat, int n, int h, int w, int c, const float *boxes, const int *box_image, int n_boxes, int crop,
+                     float *out)
+{
+    // every product and sum rounded on its own in this kernel (no fused multiply-add): whether the last sample of a box
+    // that ends exactly on the feature map's border is inside (<= h-1) or extrapolated (0) hangs on the last bit of in_y /
+    // in_x, and tf.image.crop_and_resize (and the oracle) round each operation
+#pragma clang fp contract(off)
+    const int half = crop / 2, c4 = c / 4;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)n_boxes * half * half * c4)
+        return;
+    const int cq = (int)(idx % c4);
+    const int px = (int)((idx / c4) % half), py = (int)((idx / ((long long)c4 * half)) % half);
+    const int b = (int)(idx / ((long long)c4 * half * half));
+    const float y1 = boxes[b * 4 + 0], x1 = boxes[b * 4 + 1], y2 = boxes[b * 4 + 2], x2 = boxes[b * 4 + 3];
+    const int img = box_image[b];
+    const float hs = (y2 - y1) * (float)(h - 1) / (float)(crop - 1);
+    const float ws = (x2 - x1) * (float)(w - 1) / (float)(crop - 1);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int y = 2 * py + dy, x = 2 * px + dx;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float in_y = y1 * (float)(h - 1) + (float)y * hs;
+            const float in_x = x1 * (float)(w - 1) + (float)x * ws;
+            if (img >= 0 && img < n && in_y >= 0.0f && in_y <= (float)(h - 1) && in_x >= 0.0f && in_x <= (float)(w - 1)) {
+                const int ty = (int)floorf(in_y), by = (int)ceilf(in_y);
+                const int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
+                const float fy = in_y - (float)ty, fx = in_x - (float)lx;
+                const float *base = feat + (long long)img * h * w * c + cq * 4;
+                const float4 tl = *reinterpret_cast<const float4 *>(base + ((long long)ty * w + lx) * c);
+                const float4 tr = *reinterpret_cast<const float4 *>(base + ((long long)ty * w + rx) * c);
+                const float4 bl = *reinterpret_cast<const float4 *>(base + ((long long)by * w + lx) * c);
+                const float4 br = *reinterpret_cast<const float4 *>(base + ((long long)by * w + rx) * c);
+                auto lerp2 = [&](float a, float bb, float cc, float d) {
+                    const float top = a + (bb - a) * fx, bot = cc + (d - cc) * fx;
+                    return top + (bot - top) * fy;
+                };
+                v = make_float4(lerp2(tl.x, tr.x, bl.x, br.x), lerp2(tl.y, tr.y, bl.y, br.y), lerp2(tl.z, tr.z, bl.z, br.z),
+                                lerp2(tl.w, tr.w, bl.w, br.w));
+            }
+            m.x = fmaxf(m.x, v.x);
+            m.y = fmaxf(m.y, v.y);
+            m.z = fmaxf(m.z, v.z);
+            m.w = fmaxf(m.w, v.w);
+        }
+    *reinterpret_cast<float4 *>(out + (((long long)b * half + py) * half + px) * c + cq * 4) = m;
+}
+
 // spatial mean of [n, hw, c] -> [n, c] (sum in index order, then / hw)
 __global__ void __launch_bounds__(256) det_avgpool_kernel(const float *in, long long n, int hw, int c, float *out)
 {
@@ -616,7 +671,7 @@ gs_status gs_detector_forward(gs_detector *h, const uint8_t *images_rgb, int n, 
     const Piece pM = piece((size_t)n * K1 * (K1 / 64) * 8);
     const Piece pK1 = piece((size_t)n * P * 4), pN1 = piece((size_t)n * 4);
     const Piece pP = piece((size_t)n * P * 16), pPn = piece((size_t)n * P * 16), pBi = piece((size_t)n * P * 4);
-    const Piece pC = piece((size_t)n * P * DET_CROP * DET_CROP * DET_CF * 4);
+    const Piece pC = piece((size_t)n * P * 49 * DET_CH * 4);      // box-head intermediates (the 14x14 crops are never materialised)
     const Piece pC2 = piece((size_t)n * P * 49 * DET_CF * 4);
     const Piece pH = piece((size_t)n * P * 6 * 4), pS2 = piece((size_t)n * P * 4), pB2 = piece((size_t)n * P * 16);
     const Piece pI2 = piece((size_t)n * K2 * 4), pS2s = piece((size_t)n * K2 * 4), pB2s = piece((size_t)n * K2 * 16);
@@ -664,9 +719,8 @@ gs_status gs_detector_forward(gs_detector *h, const uint8_t *images_rgb, int n, 
     hipLaunchKernelGGL(det_gather_proposals_kernel, dim3(nblk((long long)n * P)), dim3(256), 0, s, F(pB1), I(pK1), n, K1, Hf, Wf, F(pP),
                        F(pPn), I(pBi));
     // ---- box head on crop_and_resize'd features
-    DET_TRY(gs_roialign(F(pF), n, hf, wf, DET_CF, F(pPn), I(pBi), n * P, DET_CROP, F(pC), s));
-    hipLaunchKernelGGL(det_maxpool_kernel, dim3(nblk((long long)n * P * 49 * (DET_CF / 4))), dim3(256), 0, s, F(pC), (long long)n * P, DET_CROP,
-                       DET_CROP, DET_CF, 2, 2, 0, 7, 7, F(pC2));
+    hipLaunchKernelGGL(det_crop_pool_kernel, dim3(nblk((long long)n * P * 49 * (DET_CF / 4))), dim3(256), 0, s, F(pF), n, hf, wf, DET_CF, F(pPn),
+                       I(pBi), n * P, DET_CROP, F(pC2));
     DET_TRY(conv(d, d.h1, F(pC2), n * P, 7, 7, 1, F(pC), s));             // [nP,7,7,128]
     DET_TRY(conv(d, d.h2, F(pC), n * P, 7, 7, 1, F(pC2), s));             // [nP,4,4,128]
     hipLaunchKernelGGL(det_avgpool_kernel, dim3(nblk((long long)n * P * DET_CH)), dim3(256), 0, s, F(pC2), (long long)n * P, 16, DET_CH, F(pC));
