@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("GLOMSEG_LIB", LIB_PATH)
 GS_OK = 0
 GS_IN_U8_BGR_NHWC = 0
 GS_IN_F32_NCHW = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 STATUS_NAMES = {0: "GS_OK", 1: "GS_ERR_INVALID", 2: "GS_ERR_HIP", 3: "GS_ERR_NOMEM", 4: "GS_ERR_UNSUPPORTED",
                 5: "GS_ERR_NODEVICE"}

@@ -17,11 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------------------------
 // conv2d NHWC: GEMM-M = output pixels (32 per wave), GEMM-N = output channels (32 per wave, on the
 // lanes, so NHWC stores are 128-byte rows), GEMM-K = (ky,kx,cin) two at a time.
-struct ConvNhwcArgs {
-    const float *in, *w, *bias;
-    float *out;
-    int n, h, w_, cin, kh, kw, cout, stride, pad, relu, ho, wo;
-};
+// (ConvNhwcArgs: gs_internal.h)
 
 __global__ void __launch_bounds__(256) conv2d_nhwc_kernel(const ConvNhwcArgs a)
 {
@@ -85,6 +81,11 @@ struct NhwcChunk {
     float b[2][4];   // [channel tile][k-step]
 };
 
+// WP4: the weights are pre-packed [k / 4][cout][4] (k = (tap, input channel) flattened; conv2d_nhwc_pack4), so that the
+// four k-steps of a lane's channel come with ONE 16-byte load instead of four dword loads from four weight rows
+// (10 -> 4 vector-memory instructions per 16 MFMAs).  The public gs_conv2d_nhwc takes TensorFlow's [kh,kw,cin,cout] as is;
+// handles that own their weights (gs_detector) pack them once.
+template <bool WP4>
 __global__ void __launch_bounds__(256) conv2d_nhwc_tiled_kernel(const ConvNhwcArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -117,28 +118,60 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_tiled_kernel(const ConvNhwcAr
     const int nchunk = a.cin / 8;
     const int total = a.kh * a.kw * nchunk;
 
-    auto fetch = [&](int it, NhwcChunk &q) {
-        const int tap = it / nchunk, c = (it - tap * nchunk) * 8;
-        const int ky = tap / a.kw, kx = tap - ky * a.kw;
+    // Fetch iterator over (tap, 8-channel chunk), chunk fastest.  Everything that depends on the tap -- the two input
+    // positions, their validity, the byte offsets of the lane's first activation and weight -- is computed once per tap;
+    // inside a tap a fetch only adds the chunk's constant strides (no divisions, no 64-bit address arithmetic per chunk:
+    // with those in every fetch the VALU work beside 16 MFMAs held the kernel at 46 % of the matrix peak).
+    int f_cch = 0, f_ky = 0, f_kx = 0, f_tap = 0;
+    int f_aoff[2], f_woff;
+    auto set_tap = [&]() {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int iy = oy[t] * a.stride - a.pad + ky, ix = ox[t] * a.stride - a.pad + kx;
+            const int iy = oy[t] * a.stride - a.pad + f_ky, ix = ox[t] * a.stride - a.pad + f_kx;
             const bool ok = pv[t] && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w_;
-            const long long off = (((ibase[t] + iy) * a.w_ + ix) * a.cin + c + 4 * kq) * 4;
-            const nhwc_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? (int)off : OOB, 0, 0);
+            f_aoff[t] = ok ? (int)((((ibase[t] + iy) * a.w_ + ix) * a.cin + 4 * kq) * 4) : OOB;
+        }
+        f_woff = WP4 ? (((f_tap * a.cin) / 4 + kq) * a.cout + co0 + r) * 16 : ((f_tap * a.cin + 4 * kq) * a.cout + co0 + r) * 4;
+    };
+    set_tap();
+    const int wstep = WP4 ? 2 * a.cout * 16 : 8 * a.cout * 4;   // bytes between the weights of consecutive chunks
+    auto fetch = [&](NhwcChunk &q) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            // (an invalid position keeps its out-of-range offset: OOB + chunk stride is still beyond the descriptor)
+            const nhwc_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, f_aoff[t] == OOB ? OOB : f_aoff[t] + f_cch * 32, 0, 0);
             const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];   // (bit_cast straight from v[i] reads element 0)
             q.a[t][0] = __builtin_bit_cast(float, e0);
             q.a[t][1] = __builtin_bit_cast(float, e1);
             q.a[t][2] = __builtin_bit_cast(float, e2);
             q.a[t][3] = __builtin_bit_cast(float, e3);
         }
-        const int wrow = ((tap * a.cin + c + 4 * kq) * a.cout + co0 + r) * 4;
+        const int wrow = f_woff + f_cch * wstep;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u) {
+            if (WP4) {
+                const nhwc_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, cv[u] ? wrow + 32 * u * 16 : OOB, 0, 0);
+                const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+                q.b[u][0] = __builtin_bit_cast(float, e0);
+                q.b[u][1] = __builtin_bit_cast(float, e1);
+                q.b[u][2] = __builtin_bit_cast(float, e2);
+                q.b[u][3] = __builtin_bit_cast(float, e3);
+                continue;
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 q.b[u][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                           rw, cv[u] ? wrow + (s * a.cout + 32 * u) * 4 : OOB, 0, 0));
+        }
+        if (++f_cch == nchunk) {   // (uniform) next tap
+            f_cch = 0;
+            ++f_tap;
+            if (++f_kx == a.kw) {
+                f_kx = 0;
+                ++f_ky;
+            }
+            set_tap();
+        }
     };
 
     f32x16 acc[2][2];
@@ -148,10 +181,10 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_tiled_kernel(const ConvNhwcAr
         for (int u = 0; u < 2; ++u)
             acc[t][u] = (f32x16)(0.0f);
     NhwcChunk cur, nxt;
-    fetch(0, cur);
+    fetch(cur);
     for (int it = 0; it < total; ++it) {
         if (it + 1 < total)
-            fetch(it + 1, nxt);
+            fetch(nxt);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -572,6 +605,39 @@ confusion_kernel(const unsigned char *pred, const unsigned char *gt, long long n
 
 using namespace gs;
 
+namespace gs {
+
+bool conv2d_nhwc_can_pack4(int n, int h, int w, int cin, int kh, int kw, int cout)
+{
+    return cin % 8 == 0 && (long long)n * h * w * cin * 4 < 0x7fffffffLL && (long long)kh * kw * cin * cout * 4 < 0x7fffffffLL;
+}
+
+// [kh,kw,cin,cout] -> [(kh*kw*cin) / 4][cout][4]  (host)
+void conv2d_nhwc_pack4(const float *w, int kh, int kw, int cin, int cout, float *dst)
+{
+    const int K = kh * kw * cin;
+    for (int k = 0; k < K; ++k)
+        for (int co = 0; co < cout; ++co)
+            dst[((size_t)(k / 4) * cout + co) * 4 + (k & 3)] = w[(size_t)k * cout + co];
+}
+
+gs_status conv2d_nhwc_packed4(ConvNhwcArgs a, hipStream_t stream)
+{
+    a.ho = (a.h + 2 * a.pad - a.kh) / a.stride + 1;
+    a.wo = (a.w_ + 2 * a.pad - a.kw) / a.stride + 1;
+    const long long npix = (long long)a.n * a.ho * a.wo;
+    if (a.ho <= 0 || a.wo <= 0 || !conv2d_nhwc_can_pack4(a.n, a.h, a.w_, a.cin, a.kh, a.kw, a.cout)) {
+        set_error("conv2d_nhwc_packed4: shape not supported by the packed-weight kernel");
+        return GS_ERR_UNSUPPORTED;
+    }
+    dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((a.cout + 63) / 64));
+    hipLaunchKernelGGL(conv2d_nhwc_tiled_kernel<true>, grid, dim3(256), 0, stream, a);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+}  // namespace gs
+
 extern "C" {
 
 gs_status gs_crop_preprocess(const uint8_t *crop_bgr, int h, int w, const float mean[3], const float std[3], int out_h,
@@ -672,7 +738,7 @@ gs_status gs_conv2d_nhwc(const float *in, int n, int h, int w, int cin, const fl
     // tiled kernel: 8-channel chunks, 32-bit byte offsets into the input and the weights
     if (cin % 8 == 0 && (long long)n * h * w * cin * 4 < 0x7fffffffLL && (long long)kh * kw * cin * cout * 4 < 0x7fffffffLL) {
         dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((cout + 63) / 64));
-        hipLaunchKernelGGL(conv2d_nhwc_tiled_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
+        hipLaunchKernelGGL(conv2d_nhwc_tiled_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
         GS_HIP(hipGetLastError());
         return GS_OK;
     }

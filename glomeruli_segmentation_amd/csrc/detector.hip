@@ -44,7 +44,6 @@ __global__ void __launch_bounds__(256) det_preprocess_kernel(const unsigned char
     const long long p = idx >> 2;
     const int x = (int)(p % w2), y = (int)((p / w2) % h2), img = (int)(p / ((long long)w2 * h2));
     const int sy = 2 * y + (q >> 1), sx = 2 * x + (q & 1);
-    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // q == 3 also writes the zero padding channels 12..15 (as .w of its store below)
     float r = 0.0f, g = 0.0f, b = 0.0f;
     if (sy < h && sx < w) {
         const unsigned char *s = in + (((long long)img * h + sy) * w + sx) * 3;
@@ -56,13 +55,8 @@ __global__ void __launch_bounds__(256) det_preprocess_kernel(const unsigned char
     o[0] = r;
     o[1] = g;
     o[2] = b;
-    if (q == 3) {
-        float *z = out + p * 16 + 12;
-        z[0] = v.x;
-        z[1] = v.y;
-        z[2] = v.z;
-        z[3] = v.w;
-    }
+    if (q == 3)   // the thread of the last quad position also writes the four zero padding channels 12..15
+        *reinterpret_cast<float4 *>(out + p * 16 + 12) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // max-pool, NHWC, window k, stride s, padding pad (padding never wins: -inf); 4 channels per thread
@@ -544,7 +538,8 @@ static inline unsigned nblk(long long items) { return (unsigned)((items + 255) /
 
 static gs_status conv(const Detector &d, const DetLayer &l, const float *in, int n, int h, int w, int relu, float *out, hipStream_t s)
 {
-    return gs_conv2d_nhwc(in, n, h, w, l.cin, d.dblob + l.w, l.k, l.k, l.cout, d.dblob + l.b, l.stride, l.pad, relu, out, s);
+    ConvNhwcArgs a{in, d.dblob + l.w, d.dblob + l.b, out, n, h, w, l.cin, l.k, l.k, l.cout, l.stride, l.pad, relu, 0, 0};
+    return conv2d_nhwc_packed4(a, s);
 }
 static inline int conv_out(int x, const DetLayer &l) { return (x + 2 * l.pad - l.k) / l.stride + 1; }
 
@@ -594,7 +589,9 @@ gs_status gs_detector_create(const float *blob, const gs_layer_desc *table, int 
         l.stride = stride;
         l.pad = pad;
         l.w = (long long)host.size();
-        host.insert(host.end(), blob + wd->offset, blob + wd->offset + (size_t)k * k * cin * cout);
+        host.resize(host.size() + (size_t)k * k * cin * cout);
+        // every layer of this graph has cin % 8 == 0: weights go to the device in the packed [K/4][cout][4] form
+        conv2d_nhwc_pack4(blob + wd->offset, k, k, cin, cout, host.data() + l.w);
         l.b = (long long)host.size();
         host.insert(host.end(), blob + bd->offset, blob + bd->offset + cout);
         while (host.size() % 4)
@@ -649,9 +646,9 @@ gs_status gs_detector_forward(gs_detector *h, const uint8_t *images_rgb, int n, 
     const int h8 = conv_out(h4, d.c3), w8 = conv_out(w4, d.c3);
     const int hf = conv_out(h8, d.c5), wf = conv_out(w8, d.c5);
     const long long cells = (long long)hf * wf, anchors = cells * DET_A;
-    // (the tiled convolution addresses a whole input tensor with 32-bit byte offsets: beyond 2 GiB gs_conv2d_nhwc falls back
-    // to its untiled kernel, still correct; the limits here are the glue kernels' own 32-bit indices)
-    GS_REQUIRE(anchors < (1 << 24) && (long long)n * DET_PRE_NMS < (1 << 30), "gs_detector_forward: batch too large (n=%d)", n);
+    // (the tiled convolution addresses a whole input tensor with 32-bit byte offsets)
+    GS_REQUIRE(anchors < (1 << 24) && (long long)n * h2 * w2 * 16 * 4 < 0x7fffffffLL && (long long)n * DET_PROPOSALS * 49 * DET_CF * 4 < 0x7fffffffLL,
+               "gs_detector_forward: batch too large (n=%d windows of %dx%d): split it", n, height, width);
     const int P = DET_PROPOSALS, K1 = DET_PRE_NMS, K2 = 512;
     // workspace carve-up (floats unless noted)
     struct Piece { size_t off, bytes; };

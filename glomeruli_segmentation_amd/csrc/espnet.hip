@@ -872,7 +872,7 @@ using namespace gs;
 extern "C" {
 
 const char *gs_last_error(void) { return g_err.c_str(); }
-int gs_abi_version(void) { return 1; }
+int gs_abi_version(void) { return 2; }   // 2: lanes, block hook, detector, compositor LUT
 
 // A handle = the model (weights + lane-0 workspace) plus optional extra LANES: shallow copies of the model that share
 // the device weight blob and own a workspace of their own, so that two batches can be in flight on two HIP streams

@@ -48,4 +48,15 @@ struct Act {
     size_t bytes(int n) const { return (size_t)n * sn * sizeof(float); }
 };
 
+// NHWC convolution arguments (csrc/detect_ops.hip); ho / wo are filled in by the launchers
+struct ConvNhwcArgs {
+    const float *in, *w, *bias;
+    float *out;
+    int n, h, w_, cin, kh, kw, cout, stride, pad, relu, ho, wo;
+};
+// packed-weight form of the tiled NHWC convolution for handles that own their weights (detect_ops.hip)
+bool conv2d_nhwc_can_pack4(int n, int h, int w, int cin, int kh, int kw, int cout);
+void conv2d_nhwc_pack4(const float *w, int kh, int kw, int cin, int cout, float *dst);
+gs_status conv2d_nhwc_packed4(ConvNhwcArgs a, hipStream_t stream);
+
 }  // namespace gs
