@@ -403,6 +403,35 @@ def test_contours_and_polygons():
     assert d["imagePath"] == "x.PNG" and all(len(s["points"]) >= 3 for s in d["shapes"])
 
 
+def test_contours_against_scipy_topology():
+    """the border follower pinned on what scipy.ndimage (not ours) says about the same images: one outer border per
+    8-connected component, one hole border per enclosed 4-connected background component, and the traced points are
+    exactly the foreground pixels with a background 4-neighbour (Suzuki-Abe's border points, the set
+    cv2.findContours(RETR_LIST, CHAIN_APPROX_NONE) visits -- boundary_extractor.py:33-36)"""
+    from scipy import ndimage as ndi
+    from glomeruli_segmentation_amd import contours
+    rng = np.random.default_rng(3)
+    s8, s4 = np.ones((3, 3), int), ndi.generate_binary_structure(2, 1)
+    for trial in range(8):
+        field = ndi.gaussian_filter(rng.standard_normal((120, 160)), 1 + trial)
+        img = (field > 0.02 / (1 + trial)).astype(np.uint8)
+        cs = contours.find_contours(img, simple=False)
+        _, ncomp = ndi.label(img, structure=s8)
+        bl, nb = ndi.label(1 - img, structure=s4)
+        frame = (set(bl[0, :]) | set(bl[-1, :]) | set(bl[:, 0]) | set(bl[:, -1])) - {0}
+        assert len(cs) == ncomp + (nb - len(frame)), trial
+        traced = set()
+        for c in cs:
+            traced |= set(map(tuple, c[:, 0, :].tolist()))
+        pad = np.pad(img, 1)
+        border = (img == 1) & ((pad[:-2, 1:-1] == 0) | (pad[2:, 1:-1] == 0) | (pad[1:-1, :-2] == 0) | (pad[1:-1, 2:] == 0))
+        assert traced == set(zip(*np.nonzero(border)[::-1])), trial
+        # CHAIN_APPROX_SIMPLE keeps a subset of the same points, in the same number of contours
+        simple = contours.find_contours(img, simple=True)
+        assert len(simple) == len(cs)
+        assert all(set(map(tuple, a[:, 0, :].tolist())) <= set(map(tuple, b[:, 0, :].tolist())) for a, b in zip(simple, cs))
+
+
 def test_cabi_argument_and_device_errors_without_gpu(sd1):
     """status codes + gs_last_error through the C ABI; no compute is attempted (this box has no GPU, and on a GPU
     box the same calls stop at argument validation)"""
