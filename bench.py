@@ -55,6 +55,8 @@ def parse_args(argv=None):
                                                              "kernel durations are not stretched by a co-running batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-pipeline", action="store_true")
+    ap.add_argument("--host-batches", type=int, default=24,
+                    help="batches of the pinned-host pipeline leg (rounded to a multiple of the 4 distinct batches)")
     ap.add_argument("--dry-run", action="store_true",
                     help="control flow only (spawn, rendezvous, reductions, JSON) with a no-op step on CPU/gloo: "
                          "what the CPU test suite runs; never a measurement")
@@ -343,7 +345,7 @@ def run_rank(args):
     # H2D / compute / D2H pipeline of gs_espnet_segment_host, every rank with its own buffers
     host = None
     if not args.no_host_pipeline:
-        hreps = 2 if not args.dry_run else 1
+        hreps = max(1, args.host_batches // tiles_np.shape[0]) if not args.dry_run else 1
         flat = tiles_np.reshape((-1,) + tiles_np.shape[2:])
         host_tiles = torch.from_numpy(np.concatenate([flat] * hreps))
         om = torch.zeros(host_tiles.shape[:3], dtype=torch.uint8)
@@ -361,7 +363,7 @@ def run_rank(args):
         tmax_h = max(gather_f64(el_h))
         same_all = min(gather_f64(1.0 if same else 0.0)) == 1.0
         host = {"value": round(world * host_tiles.shape[0] / tmax_h, 1), "unit": "patches/s",
-                "tiles_per_rank": int(host_tiles.shape[0]),
+                "tiles_per_rank": int(host_tiles.shape[0]), "batches_per_rank": int(host_tiles.shape[0] // nb),
                 "per_rank_patches_per_s": [round(host_tiles.shape[0] / t, 1) for t in gather_f64(el_h)],
                 "note": "pinned host in -> pinned host out, PCIe inclusive, every rank its own staging buffers; "
                         "masks equal the resident path: %s" % same_all}

@@ -194,6 +194,10 @@ constexpr int F_A_GLOBAL = 131072;
 // task ends.  Removes the separate 1x1 kernel and its re-read of the whole block output.
 constexpr int F_FUSE1X1 = 262144;
 constexpr int F_RES_RING = 524288;   // residual values through a half-slot register ring (see the kernel)
+// Stride-2 3x3 reduces: output rows y and y+1 share input row 2y+1.  Odd output rows walk their three tap rows bottom-up,
+// so that neighbouring tasks (neighbouring waves of one workgroup) ask for the shared row at the same moment -- the end of
+// the even row's k-loop, and of the odd row's -- instead of a whole task apart, when it has long left the caches.
+constexpr int F_S2_FLIP = 1048576;
 constexpr int F_X_NOLOAD = 16;  // GS_DIAG timing experiments only (results are garbage): no activation loads in the loop
 constexpr int F_X_NOLDS = 32;   // GS_DIAG: no LDS weight reads in the loop
 constexpr int F_X_NOEPI = 64;   // GS_DIAG: no epilogue at all
@@ -233,6 +237,9 @@ constexpr ConvImage conv_image(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT
 #ifndef CFG_RES_RING_DIV
 #define CFG_RES_RING_DIV 2
 #endif
+#ifndef CFG_STAGE_ROT
+#define CFG_STAGE_ROT 17   // 0 = every workgroup stages the weight image in the same order
+#endif
 constexpr int conv_min_waves(int MT, int TAPS, int NDIL, int P, int FLAGS)
 {
     return (MT == 16 && TAPS == 9 && NDIL == 5 && P == 4) ? CFG_L2_MINW : 1;
@@ -246,6 +253,8 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
     constexpr bool XMERGE_ = FLAGS & F_XMERGE;
     constexpr bool VEC = FLAGS & F_VEC;
     constexpr bool AGL = FLAGS & F_A_GLOBAL, FUSE = FLAGS & F_FUSE1X1;
+    constexpr bool S2FLIP = FLAGS & F_S2_FLIP;
+    static_assert(!S2FLIP || (STRIDE == 2 && TAPS == 9 && NDIL == 1), "F_S2_FLIP is for the stride-2 3x3 reduce");
     static_assert(kDiag || !(FLAGS & F_X_ALL), "timing / stamp variants exist in -DGS_DIAG builds only");
     constexpr int IAUX = (FLAGS & F_IN_NT) ? 2 : 0;
     constexpr int RAUX = (FLAGS & F_RES_NT) ? 2 : 0, SAUX = (FLAGS & F_ST_NT) ? 2 : 0, SAUX2 = (FLAGS & F_ST2_NT) ? 2 : 0;
@@ -355,6 +364,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         const __amdgpu_buffer_rsrc_t rsrc_n = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.in + (long long)n_n * a.in_sn), 0, a.in_img_bytes, 0x00020000);
         const int sbase_n = (a.in_off + y_n * STRIDE * a.in_pitch + (rem_n - y_n * a.strips) * XSTEP * STRIDE - (XMERGE ? 1 : 0)) * 4;
+        const bool flip = S2FLIP && (y & 1), flip_n = S2FLIP && (y_n & 1);   // (wave-uniform)
         const __amdgpu_buffer_rsrc_t rout =
             __builtin_amdgcn_make_buffer_rsrc(a.out + (long long)n * a.out_sn, 0, a.out_img_bytes, 0x00020000);
         const int sout = (a.out_off + y * a.out_pitch + x0) * 4;
@@ -422,11 +432,12 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         // of a row are consecutive steps, so two of three B loads hit lines the wave has just pulled
         // into L1.
         // operands of chunk c (dilation c / CPD, row groups (c % CPD)*G ..) into ring slots 0..D-1
-        auto fetch_b = [&](const __amdgpu_buffer_rsrc_t &rs, int sb, int c, int g, int tx) {
+        auto fetch_b = [&](const __amdgpu_buffer_rsrc_t &rs, int sb, int c, int g, int tx, bool fl) {
             const int di = c / CPD;
             const int rg = (c - di * CPD) * G + g;
-            const int ty = rg / NSTEP;
-            const int sidx = rg - ty * NSTEP;
+            const int ty0 = rg / NSTEP;
+            const int sidx = rg - ty0 * NSTEP;
+            const int ty = S2FLIP && fl ? TYN - 1 - ty0 : ty0;
             const int toff = TAPS == 9 ? ((ty - 1) * a.in_pitch + (tx - 1)) << di : TAPS == 3 ? (ty - 1) * a.in_pitch : 0;
             const int soff = sb + (toff + sidx * KL * a.in_sc) * 4;
             if (FLAGS & F_X_NOLOAD) {
@@ -444,10 +455,11 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                 bq[g * TXN + tx][p] = __builtin_bit_cast(
                     float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + p * MT * STRIDE * 4, soff, IAUX));
         };
-        auto fetch_pair = [&](const __amdgpu_buffer_rsrc_t &rs, int sb, int c, int g) {
+        auto fetch_pair = [&](const __amdgpu_buffer_rsrc_t &rs, int sb, int c, int g, bool fl) {
             const int rg = c * G + g;
-            const int ty = rg / NSTEP;
-            const int sidx = rg - ty * NSTEP;
+            const int ty0 = rg / NSTEP;
+            const int sidx = rg - ty0 * NSTEP;
+            const int ty = S2FLIP && fl ? TYN - 1 - ty0 : ty0;
             const int soff = sb + ((ty - 1) * a.in_pitch - 1 + sidx * KL * a.in_sc) * 4;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
@@ -459,11 +471,12 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                 bl[g][p][2] = __builtin_bit_cast(float, e2);
             }
         };
-        auto fetch_a = [&](int c, int g, int tx) {
+        auto fetch_a = [&](int c, int g, int tx, bool fl) {
             const int di = c / CPD;
             const int rg = (c - di * CPD) * G + g;
-            const int ty = rg / NSTEP;
-            const int sidx = rg - ty * NSTEP;
+            const int ty0 = rg / NSTEP;
+            const int sidx = rg - ty0 * NSTEP;
+            const int ty = S2FLIP && fl ? TYN - 1 - ty0 : ty0;
             const int tap = TAPS == 9 ? ty * 3 + tx : TAPS == 3 ? ty : 0;
             if (FLAGS & F_X_NOLDS) {
                 aq[g * TXN + tx] = __builtin_bit_cast(float, tap + sidx + lbase);
@@ -482,12 +495,12 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (S2P) {
-                    fetch_pair(rsrc, sbase, 0, g);
+                    fetch_pair(rsrc, sbase, 0, g, flip);
                     continue;
                 }
 #pragma unroll
                 for (int tx = 0; tx < TXN; ++tx)
-                    fetch_b(rsrc, sbase, 0, g, tx);
+                    fetch_b(rsrc, sbase, 0, g, tx, flip);
             }
         }
         if (!staged) {
@@ -495,10 +508,15 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             // round trip), every piece in flight at once; a register-staged copy loop took 9 us of a
             // 183 us launch here
             const int pieces = (a.wfloats - LDS_SRC0 + 255) / 256;
-            for (int j = wid; j < pieces; j += WAVES)
+            // every workgroup starts at a different piece, so that the 256 CUs do not ask one L2 channel for the same
+            // lines at the same moment (level-3 ESP launch 0.1888 -> 0.1866 ms, measured three times)
+            const int rot = (int)((blockIdx.x * (unsigned)CFG_STAGE_ROT) % (unsigned)(pieces > 0 ? pieces : 1));
+            for (int j0 = wid; j0 < pieces; j0 += WAVES) {
+                const int j = j0 + rot < pieces ? j0 + rot : j0 + rot - pieces;
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void *)(a.wpack + LDS_SRC0 + j * 256 + lane * 4),
                     (__attribute__((address_space(3))) void *)(lds + j * 256), 16, 0, 0);
+            }
             if (pieces > 0)
                 __syncthreads();
             staged = true;
@@ -521,7 +539,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             for (int g = 0; g < G; ++g)
 #pragma unroll
                 for (int tx = 0; tx < TXN; ++tx)
-                    fetch_a(0, g, tx);
+                    fetch_a(0, g, tx, flip);
         }
 
         prefetch_res(0);
@@ -560,19 +578,31 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             const int nx = last ? 0 : c + 1;
             const __amdgpu_buffer_rsrc_t rs = last ? rsrc_n : rsrc;
             const int sb = last ? sbase_n : sbase;
+            const bool fl = last ? flip_n : flip;
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
                 for (int tx = 0; tx < TXN; ++tx) {
                     const int u = g * TXN + tx;
+#if defined(GS_DIAG) && defined(CFG_X_MFMA_KEEP)
+                    // ceiling experiment (results are garbage): only every CFG_X_MFMA_KEEP-th k-step's matrix instructions
+                    // are issued; the operands of the others are still loaded and waited for
+                    if (u % CFG_X_MFMA_KEEP != 0) {
+#pragma unroll
+                        for (int p = 0; p < P; ++p) {
+                            const float bv = S2P ? bl[S2P ? g : 0][p][S2P ? tx : 0] : bq[S2P ? 0 : u][p];
+                            asm volatile("" ::"v"(bv), "v"(aq[u]));
+                        }
+                    } else
+#endif
 #pragma unroll
                     for (int p = 0; p < P; ++p)
                         acc[p] = M::run(aq[u], S2P ? bl[S2P ? g : 0][p][S2P ? tx : 0] : bq[S2P ? 0 : u][p], acc[p]);
                     if (!S2P)
-                        fetch_b(rs, sb, nx, g, tx);
+                        fetch_b(rs, sb, nx, g, tx, fl);
                     else if (tx == 2)
-                        fetch_pair(rs, sb, nx, g);
-                    fetch_a(nx, g, tx);
+                        fetch_pair(rs, sb, nx, g, fl);
+                    fetch_a(nx, g, tx, fl);
                     // pin the ring order: left alone, hipcc sinks the refill loads to the end of the
                     // chunk, which shrinks the prefetch distance from D steps to a few
                     __builtin_amdgcn_sched_barrier(0);

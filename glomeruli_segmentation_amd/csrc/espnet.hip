@@ -46,6 +46,7 @@ void set_error(const char *fmt, ...)
 #define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 3
 #define CFG_L3_BR_P2     32, 8,   26,  9,   1,     5,   28,   25,   2, 13
 #define CFG_L3_BR_P2F    32, 8,   26,  9,   1,     5,   28,   25,   2, 3    // with the fused 1x1: 32 more accumulators
+#define CFG_L3_BR_P2R    32, 8,   26,  9,   1,     5,   28,   25,   2, 13   // shipped fused ESP form: a third of a dilation in flight
 #define CFG_DEC_CONV     16, 8,   24,  9,   1,     1,   5,    5,    8, 3
 #define CFG_DEC_CONV_XM  16, 8,   24,  3,   1,     1,   5,    5,    8, 6
 
@@ -68,7 +69,10 @@ static constexpr bool no_vec() { return false; }
 //            against 0.032 ms for the 1x1 launch: on.  ESP blocks: beside the residual registers the second accumulator
 //            set only fits at two pixels per lane, and that form takes 0.1995 ms = exactly branch kernel + 1x1 kernel
 //            (0.167 + 0.032); with the residual through a half-slot register ring (F_RES_RING) it fits at four pixels
-//            per lane (24 registers spilled) and takes 0.193-0.197 ms: -0.03 ms per step, 1 %, measured twice.  On.
+//            per lane (24 registers spilled) and takes 0.190-0.197 ms.  Shipped since: two pixels per lane WITH that
+//            register ring and a 39-step operand ring (CFG_L3_BR_P2R, 255 registers, no spill): 0.183 ms, because half-row
+//            tasks halve the images an XCD has in flight and the reduced maps stay in its L2.  CFG_L3_FUSE_P4=1 selects
+//            the four-pixel form.
 #ifndef CFG_FUSE_L3
 #define CFG_FUSE_L3 2   // 0 off, 1 down-sampler only, 2 every block
 #endif
@@ -76,7 +80,7 @@ static constexpr bool no_vec() { return false; }
 #define CFG_FUSE_L2 1
 #endif
 #ifndef CFG_L3_FUSE_P4
-#define CFG_L3_FUSE_P4 1
+#define CFG_L3_FUSE_P4 0
 #endif
 // F_A_GLOBAL (weights from L2 through the operand ring, no LDS image): level-3 ESP block 0.167 -> 0.1715 ms, level-2
 // blocks +6-10 %, stride-2 reduces +1-8 %: the 9 us staging phase it removes is cheaper than the slower loop.  Off.
@@ -91,6 +95,13 @@ static constexpr bool no_vec() { return false; }
 #endif
 constexpr int AGL_L3 = CFG_AGL_L3 ? F_A_GLOBAL : 0, AGL_L2 = CFG_AGL_L2 ? F_A_GLOBAL : 0, AGL_S2 = CFG_AGL_S2 ? F_A_GLOBAL : 0;
 constexpr int FUSE_L3 = CFG_FUSE_L3 ? F_FUSE1X1 : 0, FUSE_L2 = CFG_FUSE_L2 ? F_FUSE1X1 : 0;
+// F_S2_FLIP (odd output rows of the stride-2 reduces walk their tap rows bottom-up, so neighbouring waves fetch the input
+// row they share together): level 3 0.160 -> 0.153 ms, beyond-L2 fetch 910 -> 693 MB; level 2 0.0957 -> 0.0909 ms,
+// 524 -> 430 MB.  On for both.
+#ifndef CFG_S2_FLIP
+#define CFG_S2_FLIP 3   // bit 0: level-2 stride-2 reduce, bit 1: level-3
+#endif
+constexpr int S2FLIP_L2 = (CFG_S2_FLIP & 1) ? F_S2_FLIP : 0, S2FLIP_L3 = (CFG_S2_FLIP & 2) ? F_S2_FLIP : 0;
 
 // Every unit-stride conv launch exists in two pixel mappings; the vector one (F_VEC) needs the output width to be a
 // multiple of P (the 9th configuration parameter).
@@ -600,7 +611,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         if (m->variant == 41)
             return launch_conv_mfma<CFG_L2_C1S, 0>(conv_args(m->a0, wb + m->l2_0.c1, m->r2[0], nullptr, n), m->num_cus, s);
 #endif
-        return launch_conv_mfma<CFG_L2_C1S, F_S2PAIR | POL_L2_C1S | AGL_S2>(conv_args(m->a0, wb + m->l2_0.c1, m->r2[0], nullptr, n), m->num_cus, s);
+        return launch_conv_mfma<CFG_L2_C1S, F_S2PAIR | POL_L2_C1S | AGL_S2 | S2FLIP_L2>(conv_args(m->a0, wb + m->l2_0.c1, m->r2[0], nullptr, n), m->num_cus, s);
     });
     // b2 = BR(131) over cat([output1, output1_0, inp2]) (Model.py:359) is fused into its producers:
     // the down-sampler stores output1_0 twice (raw for the ESP blocks, b2-normalised into planes
@@ -693,7 +704,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         if (m->variant == 41)
             return launch_conv_mfma<CFG_L3_C1S, 0>(conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n), m->num_cus, s);
 #endif
-        return launch_conv_mfma<CFG_L3_C1S, F_S2PAIR | POL_L3_C1S | AGL_S2>(conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n), m->num_cus, s);
+        return launch_conv_mfma<CFG_L3_C1S, F_S2PAIR | POL_L3_C1S | AGL_S2 | S2FLIP_L3>(conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n), m->num_cus, s);
     });
     L.run(K_L3_DOWN, px3 * (25 * 9 * 128 * 2) + (m->l3_0.fused_next ? px3 * (128 * 25 * 2) : 0), [&] {
         ConvArgs ca = conv_args(m->r3[rd3], wb + m->l3_0.br, m->cc[0], nullptr, n);
@@ -724,13 +735,16 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
 #endif
             if (fuse_next) {
 #if CFG_L3_FUSE_P4
-                // four pixels per lane with the residual through a half-slot register ring
+                // four pixels per lane with the residual through a half-slot register ring (round 2's first fused form)
                 if (ca.W % 4 == 0 && !no_vec())
                     return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_RES_RING | F_VEC | POL_L3_ESP | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
 #endif
-                // two consecutive pixels per lane: the second accumulator set does not fit beside four
+                // Two consecutive pixels per lane, a 39-step operand ring, the residual through the half-slot register
+                // ring.  A task is then half a row, so the 256 waves of an XCD have TWO images in flight instead of four
+                // and the reduced maps the taps re-read stay in that XCD's 4 MiB L2: beyond-L2 fetch of a launch
+                // 542 -> 296 MB, 0.1898 -> 0.1834 ms (profiles/README.md).
                 if (ca.W % 2 == 0 && !no_vec())
-                    return launch_conv_mfma<CFG_L3_BR_P2F, F_BNACT | F_RES | F_VEC | POL_L3_ESP | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+                    return launch_conv_mfma<CFG_L3_BR_P2R, F_BNACT | F_RES | F_RES_RING | F_VEC | POL_L3_ESP | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
                 return launch_conv_mfma<CFG_L3_BR_P2F, F_BNACT | F_RES | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
             }
             // four consecutive pixels per lane and 16-byte accesses when the width allows it (0.170 ms per
@@ -1201,13 +1215,13 @@ gs_status gs_espnet_block_forward(gs_espnet *h, int kind, int level, int index, 
         const PackedConv &pc = kind == 1 ? (level == 2 ? m.l2_0 : m.l3_0) : (level == 2 ? m.l2[index] : m.l3[index]);
         gs_status r;
         if (level == 2) {
-            r = kind == 1 ? launch_conv_mfma<CFG_L2_C1S, F_S2PAIR | POL_L2_C1S | AGL_S2>(conv_args(src, wb + pc.c1, red, nullptr, 1), m.num_cus, s)
+            r = kind == 1 ? launch_conv_mfma<CFG_L2_C1S, F_S2PAIR | POL_L2_C1S | AGL_S2 | S2FLIP_L2>(conv_args(src, wb + pc.c1, red, nullptr, 1), m.num_cus, s)
                           : launch_conv_mfma<CFG_L2_C1, POL_L2_C1>(conv_args(src, wb + pc.c1, red, nullptr, 1), m.num_cus, s);
             if (r != GS_OK) return r;
             r = kind == 1 ? launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2, CFG_L2_BR_P4>(conv_args(red, wb + pc.br, dst, nullptr, 1), m.num_cus, s)
                           : launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2, CFG_L2_BR_P4>(conv_args(red, wb + pc.br, dst, &src, 1), m.num_cus, s);
         } else {
-            r = kind == 1 ? launch_conv_mfma<CFG_L3_C1S, F_S2PAIR | POL_L3_C1S | AGL_S2>(conv_args(src, wb + pc.c1, red, nullptr, 1), m.num_cus, s)
+            r = kind == 1 ? launch_conv_mfma<CFG_L3_C1S, F_S2PAIR | POL_L3_C1S | AGL_S2 | S2FLIP_L3>(conv_args(src, wb + pc.c1, red, nullptr, 1), m.num_cus, s)
                           : launch_conv_mfma<CFG_L3_C1, POL_L3_C1>(conv_args(src, wb + pc.c1, red, nullptr, 1), m.num_cus, s);
             if (r != GS_OK) return r;
             if (kind == 1)

@@ -919,3 +919,26 @@ def test_slide_bench_shards_consistently(torch_mod):
     assert a["crops"] == b["crops"] > 0 and a["windows"] == b["windows"] > 0
     assert a["pixel_totals"] == b["pixel_totals"] and a["map_nonzero"] == b["map_nonzero"] > 0
     assert sum(a["pixel_totals"]) > 0
+
+
+def test_ensemble_bench_one_slide_per_rank(torch_mod):
+    """tools/bench_ensemble.py (BASELINE cfg 5: five folds, one slide per rank): two ranks (on this one GPU, gloo rehearsal
+    knobs) report the per-slide class totals of one rank, and a slide's totals are those of gs_espnet_ensemble_forward's
+    masks resized to the crop sizes"""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(REPO, "tools", "bench_ensemble.py"), "--size", "16000", "--slides", "2"]
+    one = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run(cmd + ["--gpus", "2"], env=dict(env, GS_BENCH_BACKEND="gloo", GS_BENCH_ONE_GPU="1"), capture_output=True,
+                         text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    b = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert a["pixel_totals_per_slide"] == b["pixel_totals_per_slide"] and len(a["pixel_totals_per_slide"]) == 2
+    assert a["crops_per_slide"] == b["crops_per_slide"] > 0 and a["folds"] == 5
+    assert all(sum(row) > 0 for row in a["pixel_totals_per_slide"])
+    assert a["pixel_totals_per_slide"][0] != a["pixel_totals_per_slide"][1]        # the slides differ (seeded per slide)

@@ -38,11 +38,15 @@ class SynthSlide:
     def read_region(self, x, y, w, h, ds):
         """uint8 RGB [h,w,3] of the level-0 rectangle starting at (x,y), sampled every `ds` pixels"""
         import numpy as np
-        xs = x + np.arange(w, dtype=np.float64) * ds
-        ys = y + np.arange(h, dtype=np.float64) * ds
+        return self.sample(x + np.arange(w, dtype=np.float64) * ds, y + np.arange(h, dtype=np.float64) * ds)
+
+    def sample(self, xs, ys):
+        """uint8 RGB [len(ys),len(xs),3] of the field at the level-0 coordinates xs (columns) x ys (rows), both ascending"""
+        import numpy as np
+        h, w = len(ys), len(xs)
         img = np.empty((h, w, 3), dtype=np.float32)
         img[:] = np.array([199.0, 170.0, 204.0], dtype=np.float32)
-        x1, y1 = xs[-1], ys[-1]
+        x, y, x1, y1 = xs[0], ys[0], xs[-1], ys[-1]
         near = (self.cx + 4 * self.sig > x) & (self.cx - 4 * self.sig < x1) & (self.cy + 4 * self.sig > y) & (self.cy - 4 * self.sig < y1)
         for k in np.nonzero(near)[0]:
             gx = np.exp(-((xs - self.cx[k]) ** 2) / (2 * self.sig[k] ** 2)).astype(np.float32)
