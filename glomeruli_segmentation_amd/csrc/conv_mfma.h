@@ -204,7 +204,8 @@ constexpr int F_X_NOEPI = 64;   // GS_DIAG: no epilogue at all
 constexpr int F_X_STAMP2 = 4096;   // GS_DIAG: [wave][64] stamps of the wave's first task: 0 start, 2+2c after the MFMA
                                    // steps of chunk c, 3+2c after the epilogue that follows chunk c
 constexpr int F_X_STAMP = 128;  // GS_DIAG: per-wave s_memrealtime stamps into a.stamp (start, staged, per-dilation, end)
-constexpr int F_X_ALL = F_X_NOLOAD | F_X_NOLDS | F_X_NOEPI | F_X_STAMP | F_X_STAMP2;
+constexpr int F_X_NOEPIMEM = 2097152;   // GS_DIAG: the epilogue's arithmetic (and fused MFMAs) but none of its residual loads / output stores
+constexpr int F_X_ALL = F_X_NOLOAD | F_X_NOLDS | F_X_NOEPI | F_X_STAMP | F_X_STAMP2 | F_X_NOEPIMEM;
 
 // Float layout of a configuration's packed image in the weight blob: [weights NDIL*TAPS*CINP*NROW | BN scale, shift,
 // alpha (3*COUT, twice with F_DUAL) | F_FUSE1X1 table NDIL*NACC*64], rounded up to whole float4s.
@@ -404,6 +405,12 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         auto load_res = [&](int di, int r) {   // residual values of accumulator register r of concat slot di
             if (!RES)
                 return;
+            if (FLAGS & F_X_NOEPIMEM) {
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    resv[r % RR][p] = __builtin_bit_cast(float, di + r + p);
+                return;
+            }
             const int nout = di == 0 ? NOUT1 : NOUT;
             const int cb = di == 0 ? 0 : NOUT1 + (di - 1) * NOUT;
             const int ch0 = M::row(r, 0);
@@ -716,7 +723,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                     else if (di + 1 < NDIL)
                         load_res(di + 1, r + RR - M::NACC);
                 }
-                if (VEC && STORE1)
+                if (VEC && STORE1 && !(FLAGS & F_X_NOEPIMEM))
                     buf_store_vec<P, SAUX>(rout, live ? vo[0] + so : OOB, o1);
                 if (VEC && DUAL)
                     buf_store_vec<P, SAUX2>(rout2, live ? vo2[0] + so2 : OOB, o2);
