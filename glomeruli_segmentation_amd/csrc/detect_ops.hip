@@ -139,7 +139,13 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_tiled_kernel(const ConvNhwcAr
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             // (an invalid position keeps its out-of-range offset: OOB + chunk stride is still beyond the descriptor)
+#if defined(GS_DIAG) && defined(DET_X_SAMECHUNK)
+            const nhwc_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, f_aoff[t] == OOB ? OOB : f_aoff[t], 0, 0);   // timing only
+#elif defined(GS_DIAG) && defined(DET_X_NOALOAD)
+            const nhwc_u4 v = {(unsigned)f_aoff[t], (unsigned)f_cch, 1u, 2u};   // timing only
+#else
             const nhwc_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, f_aoff[t] == OOB ? OOB : f_aoff[t] + f_cch * 32, 0, 0);
+#endif
             const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];   // (bit_cast straight from v[i] reads element 0)
             q.a[t][0] = __builtin_bit_cast(float, e0);
             q.a[t][1] = __builtin_bit_cast(float, e1);
@@ -194,6 +200,161 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_tiled_kernel(const ConvNhwcAr
                 for (int u = 0; u < 2; ++u)
                     acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t][s], cur.b[u][s], acc[t][u], 0, 0, 0);
         cur = nxt;
+    }
+    // D: column = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * kq (pixel)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int co = co0 + 32 * u + r;
+        if (co >= a.cout)
+            continue;
+        const float b = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const long long p = pix0 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kq;
+                if (p < npix) {
+                    float v = acc[t][u][reg] + b;
+                    if (a.relu)
+                        v = fmaxf(v, 0.0f);
+                    a.out[p * a.cout + co] = v;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv2d NHWC with packed weights for cin % 32 == 0 (the detector's 64 / 128 / 256-channel layers): the tiled kernel with
+// its activation fetch widened to a whole 128-byte line per pixel.  In NHWC a lane's pixel is cin * 4 bytes from its
+// neighbour's, so the 16-byte operand load of an 8-channel chunk uses an eighth of every line it pulls into L1, and by
+// the time the same wave wants the next 16 bytes of that line -- a whole 16-MFMA chunk later, with every other wave of
+// the CU doing the same -- the line has left the 32 KB L1: measured 86 TFLOP/s against 115 with the activation loads
+// removed.  Here a lane fetches the 64 bytes it will need from the line (its k-group's four channels of FOUR consecutive
+// chunks) with four back-to-back 16-byte loads, the partner k-group's lanes take the other 64, and the 64 MFMAs of the
+// block run on registers.  Activations double-buffered per 32-channel block, weights per 8-channel chunk.
+template <int NJ>
+struct NhwcWideA {
+    float a[2][4 * NJ];   // [pixel tile][chunk j * 4 + k-step]
+};
+struct NhwcWideW {
+    float b[2][4];    // [channel tile][k-step]
+};
+// NJ = 8-channel chunks per block (4: a whole 128-byte line per pixel)
+template <int NJ>
+__global__ void __launch_bounds__(256) conv2d_nhwc_wide_kernel(const ConvNhwcArgs a)
+{
+    static_assert(NJ % 2 == 0, "the weight registers ping-pong by chunk parity across blocks");
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int r = lane & 31, kq = lane >> 5;
+    const long long npix = (long long)a.n * a.ho * a.wo;
+    const long long pix0 = ((long long)blockIdx.x * 4 + wid) * 64;
+    const int co0 = blockIdx.y * 64;
+    if (pix0 >= npix)
+        return;
+    constexpr int OOB = 0x7ffffff0;
+    const unsigned in_bytes = (unsigned)min((long long)a.n * a.h * a.w_ * a.cin * 4, (long long)0x7fffffff);
+    const unsigned w_bytes = (unsigned)((long long)a.kh * a.kw * a.cin * a.cout * 4);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, w_bytes, 0x00020000);
+    int oy[2], ox[2];
+    long long ibase[2];
+    bool pv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const long long pix = pix0 + t * 32 + r;
+        pv[t] = pix < npix;
+        const long long pc = pv[t] ? pix : 0;
+        ox[t] = (int)(pc % a.wo);
+        oy[t] = (int)((pc / a.wo) % a.ho);
+        ibase[t] = (pc / ((long long)a.wo * a.ho)) * a.h;
+    }
+    const bool cv[2] = {co0 + r < a.cout, co0 + 32 + r < a.cout};
+    const int nblk = a.cin / (8 * NJ);
+    const int total = a.kh * a.kw * nblk;   // blocks of the flattened (tap, channel) axis
+
+    // activation iterator over (tap, block), block fastest; the tap-dependent part is computed once per tap
+    int f_blk = 0, f_ky = 0, f_kx = 0;
+    int f_aoff[2];
+    auto set_tap = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int iy = oy[t] * a.stride - a.pad + f_ky, ix = ox[t] * a.stride - a.pad + f_kx;
+            const bool ok = pv[t] && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w_;
+            f_aoff[t] = ok ? (int)((((ibase[t] + iy) * a.w_ + ix) * a.cin + 4 * kq) * 4) : OOB;
+        }
+    };
+    set_tap();
+    auto fetch_a = [&](NhwcWideA<NJ> &q) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const nhwc_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, f_aoff[t] == OOB ? OOB : f_aoff[t] + f_blk * (NJ * 32) + j * 32, 0, 0);
+                const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];   // (bit_cast straight from v[i] reads element 0)
+                q.a[t][4 * j + 0] = __builtin_bit_cast(float, e0);
+                q.a[t][4 * j + 1] = __builtin_bit_cast(float, e1);
+                q.a[t][4 * j + 2] = __builtin_bit_cast(float, e2);
+                q.a[t][4 * j + 3] = __builtin_bit_cast(float, e3);
+            }
+        if (++f_blk == nblk) {   // (uniform) next tap
+            f_blk = 0;
+            if (++f_kx == a.kw) {
+                f_kx = 0;
+                ++f_ky;
+            }
+            set_tap();
+        }
+    };
+    // weights [K / 4][cout][4]: chunk g of the flattened axis starts at row 2g (+ the lane's k-group), so the offset is linear in g
+    int w_off = (kq * a.cout + co0 + r) * 16;
+    const int wstep = 2 * a.cout * 16;
+    auto fetch_w = [&](NhwcWideW &q) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const nhwc_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, cv[u] ? w_off + 32 * u * 16 : OOB, 0, 0);
+            const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+            q.b[u][0] = __builtin_bit_cast(float, e0);
+            q.b[u][1] = __builtin_bit_cast(float, e1);
+            q.b[u][2] = __builtin_bit_cast(float, e2);
+            q.b[u][3] = __builtin_bit_cast(float, e3);
+        }
+        w_off += wstep;   // (beyond the last chunk the offset leaves the descriptor: the load returns zeros)
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            acc[t][u] = (f32x16)(0.0f);
+    NhwcWideA<NJ> a0, a1;
+    NhwcWideW w0, w1;
+    fetch_a(a0);
+    fetch_w(w0);
+    // one block: prefetch the next block's activations, then its NJ chunks on ping-pong weight registers
+    auto block = [&](const NhwcWideA<NJ> &use, NhwcWideA<NJ> &pre, bool more) __attribute__((always_inline)) {
+        if (more)
+            fetch_a(pre);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            NhwcWideW &wu = (j & 1) ? w1 : w0;
+            NhwcWideW &wp = (j & 1) ? w0 : w1;
+            fetch_w(wp);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(use.a[t][4 * j + s], wu.b[u][s], acc[t][u], 0, 0, 0);
+        }
+    };
+    for (int it = 0; it < total; it += 2) {
+        block(a0, a1, it + 1 < total);
+        if (it + 1 < total)
+            block(a1, a0, it + 2 < total);
     }
     // D: column = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * kq (pixel)
 #pragma unroll
@@ -631,7 +792,14 @@ gs_status conv2d_nhwc_packed4(ConvNhwcArgs a, hipStream_t stream)
         return GS_ERR_UNSUPPORTED;
     }
     dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((a.cout + 63) / 64));
-    hipLaunchKernelGGL(conv2d_nhwc_tiled_kernel<true>, grid, dim3(256), 0, stream, a);
+    // whole-line activation fetches where a pixel has at least a line of channels and the map is not a handful of pixels.
+    // Measured on the detector (16 windows of 1000 x 1000): 64..256-channel backbone layers 86-90 -> 98-119 TFLOP/s; the
+    // 16-channel first layer at two chunks per block 876 -> 1026 us and the box head's 7x7 -> 4x4 layer 264 -> 312 us,
+    // so those stay on the chunk-at-a-time kernel.
+    if (a.cin % 32 == 0 && a.ho * a.wo >= 64)
+        hipLaunchKernelGGL(conv2d_nhwc_wide_kernel<4>, grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(conv2d_nhwc_tiled_kernel<true>, grid, dim3(256), 0, stream, a);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -173,6 +173,7 @@ struct Model {
 #endif
     float *dblob = nullptr;
     // offsets (floats) into dblob
+    float stem_params[537] = {0};   // host copy of level1 weights + folded bn1 + folded b1: they travel as kernel arguments
     long long w1, bn1, b1, b2, b3, wcls, br, wup3, w3c, cbr0, wcc, bncc, wup2, bnu2, wconv, wconv_xm, wclassifier, wtail;
     PackedConv l2_0;
     std::vector<PackedConv> l2, l3;
@@ -579,9 +580,9 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             a.mean[i] = mean ? mean[i] : 0.0f;
             a.std[i] = stdv ? stdv[i] : 1.0f;
         }
-        a.w1 = wb + m->w1;
-        a.bn1 = wb + m->bn1;
-        a.b1 = wb + m->b1;
+        std::memcpy(a.w1, m->stem_params, sizeof(float) * 432);
+        std::memcpy(a.bn1, m->stem_params + 432, sizeof(float) * 48);
+        std::memcpy(a.b1, m->stem_params + 480, sizeof(float) * 57);
         a.a0 = view(m->a0);
         a.inp1 = view(m->inp1);
         a.N = n;
@@ -948,6 +949,9 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
     m.bn1 = bb.push(tmp.data(), 48);
     if (!fold_bn(t, e + "b1.bn", e + "b1.act", 19, tmp.data())) return GS_ERR_INVALID;
     m.b1 = bb.push(tmp.data(), 57);
+    std::memcpy(m.stem_params, bb.data.data() + m.w1, sizeof(float) * 432);
+    std::memcpy(m.stem_params + 432, bb.data.data() + m.bn1, sizeof(float) * 48);
+    std::memcpy(m.stem_params + 480, bb.data.data() + m.b1, sizeof(float) * 57);
     std::vector<float> b2f(3 * 131);
     if (!fold_bn(t, e + "b2.bn", e + "b2.act", 131, b2f.data())) return GS_ERR_INVALID;
     m.b2 = bb.push(b2f.data(), 393);

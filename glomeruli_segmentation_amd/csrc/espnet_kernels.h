@@ -84,9 +84,12 @@ __device__ __forceinline__ float bn_prelu_sel(float v, const float *bnp, int C, 
 struct StemArgs {
     const void *in;          // uint8 NHWC BGR or fp32 NCHW
     float mean[3], std[3];
-    const float *w1;         // level1.conv.weight [16][3][3][3]
-    const float *bn1;        // level1 bn+act folded [3][16]
-    const float *b1;         // b1 folded [3][19]
+    // The 537 parameters travel BY VALUE in the kernel-argument segment: read-only and alias-free by construction, so hipcc
+    // fetches them with wide scalar loads well ahead of their use.  Behind pointers they arrived as 158 single-dword scalar
+    // loads per wave, each waited for where it was used, and the kernel was bound by that latency chain.
+    float w1[432];           // level1.conv.weight [16][3][3][3]
+    float bn1[48];           // level1 bn+act folded [3][16]
+    float b1[57];            // b1 folded [3][19]
     ActV a0;                 // out: output0_cat, 19 channels, (H/2 x W/2)
     ActV inp1;               // out: raw pooled input, 3 channels (feeds sample2's second pool)
     unsigned long long *hist_zero;   // optional: per-class counters the decoder tail adds into, zeroed here (first kernel of the
@@ -154,6 +157,8 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
     // all arithmetic first, all stores last: a store between two weight reads would force hipcc to
     // re-read the (possibly aliasing) weights from memory with vector loads and a full wait each time
     float outv[19][STEM_PX], poolv[3][STEM_PX];
+    // (two output channels per v_pk_fma_f32 with the weights as SGPR pairs -- half the VALU instructions -- measured slower,
+    // 0.130 vs 0.122 ms: the kernel is bound by its load -> table -> arithmetic -> store latency chain, not by VALU issue)
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
         float s[STEM_PX];
