@@ -1,7 +1,9 @@
 // gs_espnet_*: model handle, weight packing, HBM workspace and the forward schedule.
 // Reference path replaced: module/espnet/test/Model.py ESPNet.forward (:341-378) /
 // ESPNet_Encoder.forward (:273-304) called from module/espnet/test/VisualizeResults_iou.py:123.
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <memory>
@@ -195,11 +197,8 @@ struct Model {
         unsigned long long *hh = nullptr, *dh = nullptr;
         hipEvent_t up = nullptr, done = nullptr, down = nullptr;
         int first = -1, count = 0;
-    } sl[4];   // four slots: upload of batch i+2 and download of batch i-1 overlap the compute of batches i and i+1 (two lanes)
-    // ONE upload stream, ONE download stream, one compute stream per lane: HIP multiplexes streams onto a few hardware
-    // queues, and with a copy stream per slot a download landed on the compute stream's queue every other batch and held
-    // the next batch's first kernel back by its 0.35 ms
-    hipStream_t pipe_compute = nullptr, pipe_h2d = nullptr, pipe_d2h = nullptr;
+    } sl[4];   // four slots, two per stream: the host runs up to four batches ahead of the GPU
+    hipStream_t pipe_compute = nullptr, pipe_h2d = nullptr;   // the first of the pipeline's two compute streams (even batches) and its upload stream; see gs_espnet_segment_host
     size_t pipe_in_bytes = 0, pipe_out_bytes = 0;
     int pipe_batch = 0;
 
@@ -896,7 +895,7 @@ int gs_abi_version(void) { return 2; }   // 2: lanes, block hook, detector, comp
 struct gs_espnet {
     Model m;
     std::vector<std::unique_ptr<Model>> lanes;   // lane k >= 1 is lanes[k - 1]
-    hipStream_t pipe_compute2 = nullptr;         // gs_espnet_segment_host: compute stream of lane 1
+    hipStream_t pipe_compute2 = nullptr;         // gs_espnet_segment_host: the second of its two streams (odd batches)
     Model &lane(int k) { return k == 0 ? m : *lanes[k - 1]; }
 };
 
@@ -1064,7 +1063,6 @@ void gs_espnet_destroy(gs_espnet *h)
     free_pipeline(h->m);
     if (h->m.pipe_compute) hipStreamDestroy(h->m.pipe_compute);
     if (h->m.pipe_h2d) hipStreamDestroy(h->m.pipe_h2d);
-    if (h->m.pipe_d2h) hipStreamDestroy(h->m.pipe_d2h);
     if (h->pipe_compute2) hipStreamDestroy(h->pipe_compute2);
     for (auto &l : h->lanes) {
         for (auto &ev : l->events) {
@@ -1120,7 +1118,7 @@ gs_status gs_espnet_set_lanes(gs_espnet *h, int n_lanes)
         l->profile = false;
         for (auto &s : l->sl)
             s = Model::Slot();
-        l->pipe_compute = l->pipe_h2d = l->pipe_d2h = nullptr;
+        l->pipe_compute = l->pipe_h2d = nullptr;
         l->pipe_in_bytes = l->pipe_out_bytes = 0;
         l->pipe_batch = 0;
         h->lanes.push_back(std::move(l));
@@ -1358,14 +1356,29 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         }
         return e != hipSuccess;
     };
+    // Three streams.  Uploads run ahead on their own stream, which never waits for anything on the GPU.  Batch b's forward
+    // AND its download (SDMA, see below) are on compute stream b % 2, in order, behind one wait for the batch's
+    // upload; with two lanes the two compute streams have no dependency on each other, with one lane (a single workspace)
+    // each forward also waits for the previous batch's.
+    // (Round 2 first had a download stream as well, chained to the forward by an event.  HIP multiplexes streams onto a few
+    // hardware queues and a queue runs its packets in order whatever stream they came from: the download's wait-for-the-
+    // forward packet sat in front of later uploads, and in the rocprofv3 timeline every batch's first kernel -- and the
+    // upload two batches ahead -- started only when the previous batch's download had ended: 0.4 ms lost per batch.  With
+    // upload, forward and download of a batch all on one stream the two streams fell into step and copied at the same
+    // time.  No packet that waits for a kernel may sit on a stream that others might queue behind.)
+    // The three streams get three different priorities, because HIP keeps a separate pool of hardware queues per priority:
+    // whatever other streams the process has made (torch's, the engine's lane streams), these three never share a queue
+    // with each other.  (With equal priorities and two torch streams made first, the same pipeline ran at 9.2 k instead of
+    // 10.4 k patches/s.)  The upload stream is the high one; the two compute streams differ only nominally.
+    int prio_lo = 0, prio_hi = 0;
+    fail(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi), "hipDeviceGetStreamPriorityRange");   // (least, greatest): numerically lo >= hi
+    const int prio_mid = (prio_lo + prio_hi) / 2;
     if (!m.pipe_compute)
-        fail(hipStreamCreateWithFlags(&m.pipe_compute, hipStreamNonBlocking), "hipStreamCreate");
-    if (nl > 1 && !h->pipe_compute2)
-        fail(hipStreamCreateWithFlags(&h->pipe_compute2, hipStreamNonBlocking), "hipStreamCreate");
+        fail(hipStreamCreateWithPriority(&m.pipe_compute, hipStreamNonBlocking, prio_mid), "hipStreamCreate");
+    if (!h->pipe_compute2)
+        fail(hipStreamCreateWithPriority(&h->pipe_compute2, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
     if (!m.pipe_h2d)
-        fail(hipStreamCreateWithFlags(&m.pipe_h2d, hipStreamNonBlocking), "hipStreamCreate");
-    if (!m.pipe_d2h)
-        fail(hipStreamCreateWithFlags(&m.pipe_d2h, hipStreamNonBlocking), "hipStreamCreate");
+        fail(hipStreamCreateWithPriority(&m.pipe_h2d, hipStreamNonBlocking, prio_hi), "hipStreamCreate");
     if (m.pipe_in_bytes < in_b * batch || m.pipe_out_bytes < out_b * batch || m.pipe_batch < batch) {
         free_pipeline(m);
         for (int i = 0; i < NSLOT; ++i) {
@@ -1397,11 +1410,27 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         s.first = -1;
     };
     int slot = 0, bi = 0;
+#ifdef GS_DIAG
+    // host-side timeline of the loop (GS_PIPE_TRACE=1): where does the enqueueing thread wait?
+    const bool ptrace = std::getenv("GS_PIPE_TRACE") != nullptr;
+    const auto pt0 = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what) {
+        if (ptrace && bi < 12)
+            std::fprintf(stderr, "pipe %2d %-10s %9.1f us\n", bi, what,
+                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - pt0).count());
+    };
+    const int pskip = std::getenv("GS_PIPE_SKIP") ? std::atoi(std::getenv("GS_PIPE_SKIP")) : 0;   // 1: no uploads, 2: no downloads (timing only)
+#else
+    auto stamp = [](const char *) {};
+    constexpr int pskip = 0;
+#endif
     for (int first = 0; first < n_tiles && rc == GS_OK; first += batch, slot = (slot + 1) % NSLOT, ++bi) {
         Slot &s = sl[slot];
         const int lane = bi % nl;
-        hipStream_t compute = lane == 0 ? m.pipe_compute : h->pipe_compute2;
+        hipStream_t compute = (bi & 1) == 0 ? m.pipe_compute : h->pipe_compute2;
+        stamp("top");
         drain(s);   // the slot's previous batch must have left its pinned buffers
+        stamp("drained");
         if (rc != GS_OK) break;
         const int cnt = n_tiles - first < batch ? n_tiles - first : batch;
         const uint8_t *src = tiles + (size_t)first * in_b;
@@ -1410,19 +1439,35 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
             src = s.hin;
         }
         // (the slot's device buffers: its previous batch was drained above, i.e. computed and downloaded)
-        if (fail(hipMemcpyAsync(s.din, src, in_b * cnt, hipMemcpyHostToDevice, m.pipe_h2d), "H2D copy")) break;
+        if (!(pskip & 1) || bi < NSLOT)
+            if (fail(hipMemcpyAsync(s.din, src, in_b * cnt, hipMemcpyHostToDevice, m.pipe_h2d), "H2D copy")) break;
+        stamp("h2d");
         fail(hipEventRecord(s.up, m.pipe_h2d), "hipEventRecord");
         fail(hipStreamWaitEvent(compute, s.up, 0), "hipStreamWaitEvent");
+        if (nl == 1 && bi > 0)   // one workspace: this forward after the previous batch's (recorded on the other stream)
+            fail(hipStreamWaitEvent(compute, sl[(slot + NSLOT - 1) % NSLOT].done, 0), "hipStreamWaitEvent");
+        stamp("waitev");
         gs_status st2 = gs_espnet_forward_lane(h, lane, s.din, GS_IN_U8_BGR_NHWC, cnt, height, width, mean, std, nullptr,
                                                s.dout, s.dh, compute);
         if (st2 != GS_OK) { rc = st2; break; }
+        stamp("forward");
         fail(hipEventRecord(s.done, compute), "hipEventRecord");
-        fail(hipStreamWaitEvent(m.pipe_d2h, s.done, 0), "hipStreamWaitEvent");
-        fail(hipMemcpyAsync(out_pinned ? masks + (size_t)first * out_b : s.hout, s.dout, out_b * cnt, hipMemcpyDeviceToHost, m.pipe_d2h), "D2H copy");
+        stamp("waitdone");
+        // Results -> pinned host memory through hipMemcpy2DAsync: on this stack a plain hipMemcpyAsync(DeviceToHost) runs as a
+        // blit KERNEL (__amd_rocclr_copyBuffer) and the rectangular copy goes to the SDMA engine (rocprofv3: a memory-copy
+        // record instead of a kernel, the same 53 GB/s).  A copy kernel of any size costs the pipeline its whole 0.33 ms:
+        // the level-2 / level-3 launches need every CU's full register file (one workgroup per CU), so every CU that holds a
+        // copy wave sends a launch into a second round -- measured 3.29 ms per batch with a 48-workgroup copy kernel, 2.96
+        // without the download, 2.93 without any copy.
+        uint8_t *hdst = out_pinned ? masks + (size_t)first * out_b : s.hout;
+        unsigned long long *hhdst = out_pinned ? hist + (size_t)first * 5 : s.hh;
+        if (!(pskip & 2))
+            fail(hipMemcpy2DAsync(hdst, out_b, s.dout, out_b, out_b, cnt, hipMemcpyDeviceToHost, compute), "D2H copy");
         if (hist || !out_pinned)
-            fail(hipMemcpyAsync(out_pinned ? reinterpret_cast<void *>(hist + (size_t)first * 5) : reinterpret_cast<void *>(s.hh), s.dh,
-                                sizeof(unsigned long long) * 5 * cnt, hipMemcpyDeviceToHost, m.pipe_d2h), "D2H copy");
-        fail(hipEventRecord(s.down, m.pipe_d2h), "hipEventRecord");
+            fail(hipMemcpy2DAsync(hhdst, sizeof(unsigned long long) * 5 * cnt, s.dh, sizeof(unsigned long long) * 5 * cnt,
+                                  sizeof(unsigned long long) * 5 * cnt, 1, hipMemcpyDeviceToHost, compute), "D2H copy");
+        fail(hipEventRecord(s.down, compute), "hipEventRecord");
+        stamp("d2h");
         s.first = first;
         s.count = cnt;
     }
