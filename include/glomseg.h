@@ -94,8 +94,10 @@ gs_status gs_espnet_forward_lane(gs_espnet *h, int lane, const void *in, int in_
                                  unsigned long long *hist, void *hip_stream);
 
 /* Host-to-host batch pipeline: n_tiles uint8 BGR tiles in (pageable or pinned) host memory are
- * staged through pinned double buffers with hipMemcpyAsync on two streams, `batch` tiles per step,
- * masks (and optional per-tile histograms) come back to host memory.  Replaces the whole loop
+ * uploaded on a stream of their own (page-locked buffers in place, pageable ones through pinned staging slots), `batch`
+ * tiles per step; each batch's forward and its download (SDMA) run in order on one of two compute streams; up to four
+ * batches are queued ahead.  Masks (and optional per-tile histograms) come back to host memory; the call returns when
+ * all of them have.  Replaces the whole loop
  * VisualizeResults_iou.py:100-156 for a list of equal-size tiles. */
 gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles, int height, int width,
                                  const float mean[3], const float std[3], int batch, uint8_t *masks,
