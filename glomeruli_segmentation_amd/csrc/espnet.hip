@@ -1370,7 +1370,6 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         return at.type == hipMemoryTypeHost;
     };
     const bool in_pinned = is_pinned(tiles), out_pinned = is_pinned(masks) && (!hist || is_pinned(hist));
-    // two slots: while slot s computes, slot s^1 uploads the next batch and downloads the previous masks
     Model &m = h->m;
     using Slot = Model::Slot;
     Slot *sl = m.sl;
@@ -1486,7 +1485,7 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         // copy wave sends a launch into a second round -- measured 3.29 ms per batch with a 48-workgroup copy kernel, 2.96
         // without the download, 2.93 without any copy.
         uint8_t *hdst = out_pinned ? masks + (size_t)first * out_b : s.hout;
-        unsigned long long *hhdst = out_pinned ? hist + (size_t)first * 5 : s.hh;
+        unsigned long long *hhdst = (out_pinned && hist) ? hist + (size_t)first * 5 : s.hh;
         if (!(pskip & 2))
             fail(hipMemcpy2DAsync(hdst, out_b, s.dout, out_b, out_b, cnt, hipMemcpyDeviceToHost, compute), "D2H copy");
         if (hist || !out_pinned)
