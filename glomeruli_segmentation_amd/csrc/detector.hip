@@ -393,33 +393,59 @@ det_nms_mask_kernel(const float *boxes, const float *scores, int K, float thr, f
         }
     mask[((long long)img * K + row) * words + colb] = bits;
 }
-// ... and one wave per image walks the sorted list.  keep[img][0..max_out) = kept positions (-1 beyond the count).
-__global__ void __launch_bounds__(64)
+// ... and one workgroup per image walks the sorted list: all 256 threads first pull the image's whole suppression matrix
+// (K x K/64 words: 128 KB at K = 1024) into LDS in one coalesced sweep, then the first wave scans it serially with the
+// removed-set in registers (lane t holds word t) -- a kept candidate costs an LDS read instead of a dependent round trip to
+// L2 (148 -> see profiles/ us for 16 images of 1024 candidates).  keep[img][0..max_out) = kept positions (-1 beyond the count).
+__global__ void __launch_bounds__(256)
 det_nms_scan_kernel(const unsigned long long *mask, const float *scores, int K, float score_thr, int max_out, int *keep, int *n_keep)
 {
-    __shared__ unsigned long long removed[16];   // K <= 1024
-    const int img = blockIdx.x, words = K / 64;
-    if (threadIdx.x < 16)
-        removed[threadIdx.x] = 0;
+    extern __shared__ unsigned long long rows[];   // [K][words]
+    __shared__ int n_valid_sh;
+    const int img = blockIdx.x, words = K / 64, tid = threadIdx.x;
+    if (tid == 0)
+        n_valid_sh = 0;
     __syncthreads();
+    const unsigned long long *mimg = mask + (long long)img * K * words;
+    for (int e = tid; e < K * words; e += 256)
+        rows[e] = mimg[e];
     const float *simg = scores + (long long)img * K;
+    int cnt = 0;
+    for (int e = tid; e < K; e += 256)
+        cnt += simg[e] > score_thr ? 1 : 0;   // sorted descending: the valid candidates are a prefix
+    if (cnt)
+        atomicAdd(&n_valid_sh, cnt);
+    __syncthreads();
+    if (tid >= 64)
+        return;
+    const int n_valid = n_valid_sh;
+    unsigned long long removed = 0;   // lane t: word t of the removed set
     int kept = 0;
-    for (int i = 0; i < K && kept < max_out; ++i) {
-        if (!(simg[i] > score_thr))   // sorted: nothing valid follows
-            break;
-        const bool dead = (removed[i >> 6] >> (i & 63)) & 1ull;   // wave-uniform
-        if (!dead) {
-            if (threadIdx.x == 0)
+    // word by word; inside a word jump straight to the next candidate that is still alive (most are not: the loop runs once
+    // per KEPT box, not once per candidate)
+    for (int wi = 0; wi < words && wi * 64 < n_valid && kept < max_out; ++wi) {
+        const int left = n_valid - wi * 64;
+        const unsigned long long valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+        unsigned long long done = 0;   // candidates of this word already looked at (uniform)
+        while (kept < max_out) {
+            const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)(removed & 0xffffffffull), wi);
+            const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(removed >> 32), wi);
+            const unsigned long long alive = ~(((unsigned long long)hi << 32) | lo) & valid & ~done;
+            if (alive == 0)
+                break;
+            const int b = __builtin_ctzll(alive);
+            const int i = wi * 64 + b;
+            done |= b == 63 ? ~0ull : ((2ull << b) - 1ull);
+            if (tid == 0)
                 keep[(long long)img * max_out + kept] = i;
             ++kept;
-            if ((int)threadIdx.x >= (i >> 6) && (int)threadIdx.x < words)
-                removed[threadIdx.x] |= mask[((long long)img * K + i) * words + threadIdx.x];
+            if (tid >= wi && tid < words)
+                removed |= rows[i * words + tid];
         }
-        __syncthreads();
     }
-    for (int j = kept + threadIdx.x; j < max_out; j += 64)
+    for (int j = kept + tid; j < max_out; j += 64)
         keep[(long long)img * max_out + j] = -1;
-    if (threadIdx.x == 0)
+    if (tid == 0)
         n_keep[img] = kept;
 }
 
@@ -567,6 +593,9 @@ gs_status gs_detector_create(const float *blob, const gs_layer_desc *table, int 
     std::unique_ptr<gs_detector> h(new gs_detector());
     Detector &d = h->d;
     GS_HIP(hipGetDevice(&d.device));
+    // the NMS walk keeps an image's whole suppression matrix in LDS (128 KB for the 1024 pre-NMS candidates)
+    GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(det_nms_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               DET_PRE_NMS * (DET_PRE_NMS / 64) * 8));
     std::map<std::string, const gs_layer_desc *> by_name;
     for (int i = 0; i < n_layers; ++i)
         by_name[std::string(table[i].name)] = &table[i];
@@ -711,7 +740,7 @@ gs_status gs_detector_forward(gs_detector *h, const uint8_t *images_rgb, int n, 
     hipLaunchKernelGGL(det_rpn_decode_kernel, dim3(nblk((long long)n * K1)), dim3(256), 0, s, F(pR), I(pI1), n, hf, wf, K1, Hf, Wf, F(pB1));
     hipLaunchKernelGGL(det_nms_mask_kernel, dim3(K1 / 64, K1 / 64, n), dim3(64), 0, s, F(pB1), F(pS1), K1, d.rpn_iou, 0.0f,
                        reinterpret_cast<unsigned long long *>(base + pM.off));
-    hipLaunchKernelGGL(det_nms_scan_kernel, dim3(n), dim3(64), 0, s, reinterpret_cast<unsigned long long *>(base + pM.off), F(pS1), K1, 0.0f,
+    hipLaunchKernelGGL(det_nms_scan_kernel, dim3(n), dim3(256), (size_t)K1 * (K1 / 64) * 8, s, reinterpret_cast<unsigned long long *>(base + pM.off), F(pS1), K1, 0.0f,
                        P, I(pK1), I(pN1));
     hipLaunchKernelGGL(det_gather_proposals_kernel, dim3(nblk((long long)n * P)), dim3(256), 0, s, F(pB1), I(pK1), n, K1, Hf, Wf, F(pP),
                        F(pPn), I(pBi));
@@ -729,7 +758,7 @@ gs_status gs_detector_forward(gs_detector *h, const uint8_t *images_rgb, int n, 
     hipLaunchKernelGGL(det_gather_kernel, dim3(nblk((long long)n * K2)), dim3(256), 0, s, F(pB2), I(pI2), n, P, K2, F(pB2s));
     hipLaunchKernelGGL(det_nms_mask_kernel, dim3(K2 / 64, K2 / 64, n), dim3(64), 0, s, F(pB2s), F(pS2s), K2, d.det_iou, d.det_score,
                        reinterpret_cast<unsigned long long *>(base + pM.off));
-    hipLaunchKernelGGL(det_nms_scan_kernel, dim3(n), dim3(64), 0, s, reinterpret_cast<unsigned long long *>(base + pM.off), F(pS2s), K2,
+    hipLaunchKernelGGL(det_nms_scan_kernel, dim3(n), dim3(256), (size_t)K2 * (K2 / 64) * 8, s, reinterpret_cast<unsigned long long *>(base + pM.off), F(pS2s), K2,
                        d.det_score, DET_MAX_DET, I(pK2), I(pN2));
     hipLaunchKernelGGL(det_output_kernel, dim3(nblk((long long)n * DET_MAX_DET)), dim3(256), 0, s, F(pB2s), F(pS2s), I(pK2), I(pN2), n, K2, Hf,
                        Wf, boxes, scores, classes, num);
