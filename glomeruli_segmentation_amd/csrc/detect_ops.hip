@@ -239,8 +239,9 @@ struct NhwcWideA {
 struct NhwcWideW {
     float b[2][4];    // [channel tile][k-step]
 };
-// NJ = 8-channel chunks per block (4: a whole 128-byte line per pixel)
-template <int NJ>
+// NJ = 8-channel chunks per block (4: a whole 128-byte line per pixel); WP4: weights packed [K/4][cout][4] (one 16-byte load
+// per channel tile and chunk) or TensorFlow's [kh,kw,cin,cout] as given to the public gs_conv2d_nhwc (four dword loads)
+template <int NJ, bool WP4>
 __global__ void __launch_bounds__(256) conv2d_nhwc_wide_kernel(const ConvNhwcArgs a)
 {
     static_assert(NJ % 2 == 0, "the weight registers ping-pong by chunk parity across blocks");
@@ -306,18 +307,25 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_wide_kernel(const ConvNhwcArg
             set_tap();
         }
     };
-    // weights [K / 4][cout][4]: chunk g of the flattened axis starts at row 2g (+ the lane's k-group), so the offset is linear in g
-    int w_off = (kq * a.cout + co0 + r) * 16;
-    const int wstep = 2 * a.cout * 16;
+    // weights: chunk g of the flattened (tap, channel) axis starts at k = 8g (+ 4 for the second k-group), so the offset is
+    // linear in g in both layouts
+    int w_off = WP4 ? (kq * a.cout + co0 + r) * 16 : (4 * kq * a.cout + co0 + r) * 4;
+    const int wstep = WP4 ? 2 * a.cout * 16 : 8 * a.cout * 4;
     auto fetch_w = [&](NhwcWideW &q) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const nhwc_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, cv[u] ? w_off + 32 * u * 16 : OOB, 0, 0);
-            const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
-            q.b[u][0] = __builtin_bit_cast(float, e0);
-            q.b[u][1] = __builtin_bit_cast(float, e1);
-            q.b[u][2] = __builtin_bit_cast(float, e2);
-            q.b[u][3] = __builtin_bit_cast(float, e3);
+            if (WP4) {
+                const nhwc_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, cv[u] ? w_off + 32 * u * 16 : OOB, 0, 0);
+                const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+                q.b[u][0] = __builtin_bit_cast(float, e0);
+                q.b[u][1] = __builtin_bit_cast(float, e1);
+                q.b[u][2] = __builtin_bit_cast(float, e2);
+                q.b[u][3] = __builtin_bit_cast(float, e3);
+                continue;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                q.b[u][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, cv[u] ? w_off + (s * a.cout + 32 * u) * 4 : OOB, 0, 0));
         }
         w_off += wstep;   // (beyond the last chunk the offset leaves the descriptor: the load returns zeros)
     };
@@ -797,7 +805,7 @@ gs_status conv2d_nhwc_packed4(ConvNhwcArgs a, hipStream_t stream)
     // 16-channel first layer at two chunks per block 876 -> 1026 us and the box head's 7x7 -> 4x4 layer 264 -> 312 us,
     // so those stay on the chunk-at-a-time kernel.
     if (a.cin % 32 == 0 && a.ho * a.wo >= 64)
-        hipLaunchKernelGGL(conv2d_nhwc_wide_kernel<4>, grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((conv2d_nhwc_wide_kernel<4, true>), grid, dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(conv2d_nhwc_tiled_kernel<true>, grid, dim3(256), 0, stream, a);
     GS_HIP(hipGetLastError());
@@ -906,7 +914,10 @@ gs_status gs_conv2d_nhwc(const float *in, int n, int h, int w, int cin, const fl
     // tiled kernel: 8-channel chunks, 32-bit byte offsets into the input and the weights
     if (cin % 8 == 0 && (long long)n * h * w * cin * 4 < 0x7fffffffLL && (long long)kh * kw * cin * cout * 4 < 0x7fffffffLL) {
         dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((cout + 63) / 64));
-        hipLaunchKernelGGL(conv2d_nhwc_tiled_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
+        if (cin % 32 == 0 && a.ho * a.wo >= 64)   // whole-line activation fetches (see conv2d_nhwc_packed4)
+            hipLaunchKernelGGL((conv2d_nhwc_wide_kernel<4, false>), grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
+        else
+            hipLaunchKernelGGL(conv2d_nhwc_tiled_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
         GS_HIP(hipGetLastError());
         return GS_OK;
     }

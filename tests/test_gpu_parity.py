@@ -434,8 +434,11 @@ def test_detector_primitives_self_consistency(torch_mod):
         torch.cuda.synchronize()
         assert (out.cpu() - ref).abs().max() <= 2e-4, (ci, kk)
     # the tiled kernel (cin % 8 == 0): ragged pixel and channel tiles, stride 1 and 2, with and without bias / relu
+    # ... and its whole-line-fetch form (cin % 32 == 0 and at least 64 output pixels per image)
     for (cn, hh, ww, ci, co, st, relu, use_bias) in ((2, 21, 37, 16, 70, 1, 1, True), (3, 30, 19, 24, 64, 2, 0, False),
-                                                    (1, 9, 300, 8, 130, 1, 1, True)):
+                                                    (1, 9, 300, 8, 130, 1, 1, True), (2, 21, 37, 32, 70, 1, 1, True),
+                                                    (1, 30, 19, 64, 64, 2, 0, False), (3, 11, 13, 96, 40, 1, 1, True),
+                                                    (1, 7, 9, 32, 33, 1, 0, True)):
         x = torch.randn(cn, hh, ww, ci, generator=g)
         w = torch.randn(3, 3, ci, co, generator=g) * 0.1
         bias = torch.randn(co, generator=g)
