@@ -191,10 +191,12 @@ template <int K>
 __global__ void __launch_bounds__(1024) det_topk_kernel(const float *score, int n_per, int *out_idx, float *out_score)
 {
     static_assert((K & (K - 1)) == 0 && K <= 1024, "K is a power of two, one element per thread");
-    __shared__ unsigned hist[256];
+    __shared__ unsigned hist[16][256];          // one histogram per wave: the digits of sorted-looking scores cluster, and
+                                                // 1024 threads on one set of counters serialise on the LDS atomics
+    __shared__ unsigned tot[256], suf[256];
     __shared__ unsigned long long keys[K];
-    __shared__ unsigned sh_prefix, sh_remaining, sh_count, sh_tie_base[1024];
-    const int img = blockIdx.x, tid = threadIdx.x;
+    __shared__ unsigned sh_prefix, sh_remaining, sh_count, scan[1024];
+    const int img = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
     const float *s = score + (long long)img * n_per;
     const int want = n_per < K ? n_per : K;
     // radix select on the order-preserving keys
@@ -204,26 +206,43 @@ __global__ void __launch_bounds__(1024) det_topk_kernel(const float *score, int 
     }
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        if (tid < 256)
-            hist[tid] = 0;
+        for (int e = tid; e < 16 * 256; e += 1024)
+            (&hist[0][0])[e] = 0;
         __syncthreads();
-        const unsigned prefix = sh_prefix;
+        const unsigned prefix = sh_prefix, rem = sh_remaining;   // (read by everyone before the barriers that precede their update)
         const unsigned pmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
         for (int i = tid; i < n_per; i += 1024) {
             const unsigned b = f2k(s[i]);
             if ((b & pmask) == prefix)
-                atomicAdd(&hist[(b >> shift) & 255u], 1u);
+                atomicAdd(&hist[wave][(b >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned rem = sh_remaining, d = 255;
-            for (;; --d) {   // from the top digit down: the digit that holds the rem-th largest
-                if (hist[d] >= rem || d == 0)
-                    break;
-                rem -= hist[d];
+        if (tid < 256) {
+            unsigned t = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w)
+                t += hist[w][tid];
+            tot[tid] = t;
+            suf[tid] = t;
+        }
+        __syncthreads();
+        // inclusive suffix sums over the 256 digits (suf[d] = elements with digit >= d), eight doubling steps
+        for (int step = 1; step < 256; step <<= 1) {
+            unsigned add = 0;
+            if (tid < 256 && tid + step < 256)
+                add = suf[tid + step];
+            __syncthreads();
+            if (tid < 256)
+                suf[tid] += add;
+            __syncthreads();
+        }
+        // the digit that holds the rem-th largest: suf[d + 1] < rem <= suf[d]  (d = 0 if fewer than rem elements remain)
+        if (tid < 256) {
+            const unsigned above = tid == 255 ? 0u : suf[tid + 1];
+            if ((above < rem && rem <= suf[tid]) || (tid == 0 && suf[0] < rem)) {
+                sh_prefix = prefix | ((unsigned)tid << shift);
+                sh_remaining = rem - above;
             }
-            sh_prefix = prefix | (d << shift);
-            sh_remaining = rem;
         }
         __syncthreads();
     }
@@ -246,20 +265,18 @@ __global__ void __launch_bounds__(1024) det_topk_kernel(const float *score, int 
         } else if (b == kth)
             ++my_ties;
     }
-    sh_tie_base[tid] = my_ties;
+    // exclusive scan of the 1024 tie counts (ten doubling steps)
+    scan[tid] = my_ties;
     __syncthreads();
-    if (tid == 0) {   // exclusive scan of 1024 small counts (serial: a few microseconds, once per image)
-        unsigned run = 0;
-        for (int t = 0; t < 1024; ++t) {
-            const unsigned c = sh_tie_base[t];
-            sh_tie_base[t] = run;
-            run += c;
-        }
+    for (int step = 1; step < 1024; step <<= 1) {
+        const unsigned add = tid >= step ? scan[tid - step] : 0u;
+        __syncthreads();
+        scan[tid] += add;
+        __syncthreads();
     }
-    __syncthreads();
     {
-        unsigned pos = sh_tie_base[tid];
-        const unsigned base = sh_count;   // all strictly-greater keys are in (count is final after the barrier above)
+        unsigned pos = scan[tid] - my_ties;
+        const unsigned base = sh_count;   // all strictly-greater keys are in (count is final after the barriers above)
         for (int i = lo; i < hi && pos < ties; ++i) {
             const unsigned b = f2k(s[i]);
             if (b == kth) {
@@ -269,7 +286,7 @@ __global__ void __launch_bounds__(1024) det_topk_kernel(const float *score, int 
         }
     }
     __syncthreads();
-    // bitonic sort, descending
+    // bitonic sort, descending.  Partners less than 64 apart are in the same wave: those stages need no workgroup barrier.
     for (int size = 2; size <= K; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             if (tid < K) {
@@ -283,8 +300,15 @@ __global__ void __launch_bounds__(1024) det_topk_kernel(const float *score, int 
                     }
                 }
             }
-            __syncthreads();
+            if (stride >= 64 || (stride == 1 && size >= 64))   // this stage or the next one pairs elements of different waves
+                __syncthreads();
+            else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
         }
+    __syncthreads();
     for (int i = tid; i < K; i += 1024) {
         const unsigned long long k = keys[i];
         const bool valid = i < want;
