@@ -27,8 +27,6 @@ buffers) is measured for every N beside it.  Rank 0 prints ONE JSON line.
 import argparse
 import json
 import os
-import socket
-import subprocess
 import sys
 import time
 
@@ -55,8 +53,12 @@ def parse_args(argv=None):
                                                              "kernel durations are not stretched by a co-running batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-pipeline", action="store_true")
-    ap.add_argument("--host-batches", type=int, default=24,
-                    help="batches of the pinned-host pipeline leg (rounded to a multiple of the 4 distinct batches)")
+    ap.add_argument("--host-batches", type=int, default=224,
+                    help="batches of the pinned-host pipeline leg (SURVEY 8d: >= 200 after >= 20 warm-up), run as calls of 32 "
+                         "batches cycling one set of pinned buffers")
+    ap.add_argument("--no-real-crops", action="store_true")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="test hook (--dry-run only): this rank exits with code 3 after "
+                                                              "the rendezvous, to exercise the parent's fail-fast path")
     ap.add_argument("--dry-run", action="store_true",
                     help="control flow only (spawn, rendezvous, reductions, JSON) with a no-op step on CPU/gloo: "
                          "what the CPU test suite runs; never a measurement")
@@ -64,37 +66,12 @@ def parse_args(argv=None):
 
 
 # ---------------------------------------------------------------------------------------------
-def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
 def spawn_ranks(args):
-    """Parent of a plain `bench.py --gpus N`: start one child per GPU.  Nothing here touches the GPU
-    (no torch import), so the children are the first processes of this job to initialise it."""
-    env = dict(os.environ)
-    env.setdefault("MASTER_ADDR", "127.0.0.1")
-    env.setdefault("MASTER_PORT", str(free_port()))
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env["WORLD_SIZE"] = str(args.gpus)
-    env["LOCAL_WORLD_SIZE"] = str(args.gpus)
-    procs = []
-    for r in range(args.gpus):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print("bench.py: rank(s) failed: %s" % bad, file=sys.stderr)
-        return 1
-    return 0
+    """Parent of a plain `bench.py --gpus N`: start one child per GPU and watch all of them (a rank that dies takes the job
+    down at once, with its stderr tail, instead of leaving the others in a collective until a timeout).  Nothing here
+    touches the GPU (no torch import), so the children are the first processes of this job to initialise it."""
+    from glomeruli_segmentation_amd.launch import spawn_ranks as spawn
+    return spawn(os.path.abspath(__file__), sys.argv[1:], args.gpus)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -212,6 +189,8 @@ def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    from glomeruli_segmentation_amd.launch import place_rank
+    cpus = place_rank()        # before the first GPU call: this rank's share of its GPU's NUMA node (no-op for one rank)
     if world != args.gpus:
         print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         return 2
@@ -236,6 +215,9 @@ def run_rank(args):
     elif not args.dry_run:
         torch.cuda.set_device(0)
     dev = torch.device("cpu") if args.dry_run else torch.device("cuda", torch.cuda.current_device())
+    if args.dry_run and args.fail_rank == rank:
+        print("bench.py: rank %d fails on purpose (--fail-rank)" % rank, file=sys.stderr)
+        os._exit(3)
 
     def sync():
         if not args.dry_run:
@@ -345,28 +327,62 @@ def run_rank(args):
     # H2D / compute / D2H pipeline of gs_espnet_segment_host, every rank with its own buffers
     host = None
     if not args.no_host_pipeline:
-        hreps = max(1, args.host_batches // tiles_np.shape[0]) if not args.dry_run else 1
+        nb = tiles_np.shape[1]
+        per_call = 32 if not args.dry_run else NBATCH                 # batches per call: one set of pinned buffers, cycled
+        calls = max(1, -(-args.host_batches // per_call)) if not args.dry_run else 1
         flat = tiles_np.reshape((-1,) + tiles_np.shape[2:])
-        host_tiles = torch.from_numpy(np.concatenate([flat] * hreps))
+        host_tiles = torch.from_numpy(np.concatenate([flat] * (per_call // NBATCH)))
         om = torch.zeros(host_tiles.shape[:3], dtype=torch.uint8)
         oh = torch.zeros((host_tiles.shape[0], 5), dtype=torch.int64)
         if not args.dry_run:
             host_tiles, om, oh = host_tiles.pin_memory(), om.pin_memory(), oh.pin_memory()   # caller-owned pinned buffers
-        nb = tiles_np.shape[1]
-        eng.segment_host(host_tiles[:3 * nb], mean, std, batch=nb, out_masks=om[:3 * nb], out_hist=oh[:3 * nb])
+        eng.segment_host(host_tiles, mean, std, batch=nb, out_masks=om, out_hist=oh)          # warm-up: 32 batches
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
-        hm, _ = eng.segment_host(host_tiles, mean, std, batch=nb, out_masks=om, out_hist=oh)
+        for _ in range(calls):
+            hm, _ = eng.segment_host(host_tiles, mean, std, batch=nb, out_masks=om, out_hist=oh)
         el_h = time.perf_counter() - t0
+        n_host = int(host_tiles.shape[0]) * calls
         same = bool((hm[:nb] == mask[0].cpu().numpy()).all())
         tmax_h = max(gather_f64(el_h))
         same_all = min(gather_f64(1.0 if same else 0.0)) == 1.0
-        host = {"value": round(world * host_tiles.shape[0] / tmax_h, 1), "unit": "patches/s",
-                "tiles_per_rank": int(host_tiles.shape[0]), "batches_per_rank": int(host_tiles.shape[0] // nb),
-                "per_rank_patches_per_s": [round(host_tiles.shape[0] / t, 1) for t in gather_f64(el_h)],
-                "note": "pinned host in -> pinned host out, PCIe inclusive, every rank its own staging buffers; "
-                        "masks equal the resident path: %s" % same_all}
+        host = {"value": round(world * n_host / tmax_h, 1), "unit": "patches/s",
+                "tiles_per_rank": n_host, "batches_per_rank": n_host // nb, "warmup_batches": int(host_tiles.shape[0] // nb),
+                "calls": calls, "per_rank_patches_per_s": [round(n_host / t, 1) for t in gather_f64(el_h)],
+                "note": "pinned host in -> pinned host out, PCIe inclusive, every rank its own staging buffers; every call "
+                        "fills and drains the pipeline once; masks equal the resident path: %s" % same_all}
+
+    # the path REAL crops take (VisualizeResults_iou.py:100-156 with crops that are not network-sized): the 28 crop sizes of the
+    # example slide, pageable numpy crops in -> crop-size maps + counts out through gs_espnet_segment_crops_host
+    real = None
+    if not args.no_real_crops and not args.dry_run:
+        from glomeruli_segmentation_amd.synth import synth_tile
+        ex = np.load(os.path.join(REPO, "tests", "golden", "merge.npz"))["example_boxes"]
+        base = [synth_tile(5000 + rank * 100 + k, int(b[3] - b[1]), int(b[2] - b[0]), blobs=4) for k, b in enumerate(ex)]
+        crops = base * 16                                             # 448 crops = 14 batches of 32
+        eng.segment_crops(crops, mean, std, H, W, BATCH)              # warm-up: 14 batches (staging buffers, pinned output block)
+        el_c, el_p = [], []
+        pinned = [torch.from_numpy(c).pin_memory() for c in base] * 16
+        eng.segment_crops(pinned, mean, std, H, W, BATCH)
+        for _ in range(5):                                            # 5 x 14 batches each way, median call
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            rr = eng.segment_crops(crops, mean, std, H, W, BATCH)
+            el_c.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            eng.segment_crops(pinned, mean, std, H, W, BATCH)
+            el_p.append(time.perf_counter() - t0)
+        el_c, el_p = float(np.median(el_c)), float(np.median(el_p))
+        ok = all(int(rr["counts"][i].sum()) == crops[i].shape[0] * crops[i].shape[1] for i in range(len(crops)))
+        real = {"value": round(world * len(crops) / max(gather_f64(el_c)), 1), "unit": "crops/s", "crops_per_rank": len(crops),
+                "pinned_inputs_crops_per_s": round(world * len(crops) / max(gather_f64(el_p)), 1),
+                "mean_crop_px": int(np.mean([c.shape[0] * c.shape[1] for c in base])),
+                "note": "crop sizes of the example slide's 28 boxes (tests/golden/merge.npz), pageable numpy crops in, crop-size "
+                        "maps and counts out (pinned); resample + forward + argmax + resize back per batch of 32; median of 5 calls "
+                        "of 14 batches after a warm-up call (every call fills and drains the pipeline once); "
+                        "counts cover every pixel: %s" % ok}
 
     rc = 0
     if rank == 0:
@@ -383,6 +399,8 @@ def run_rank(args):
             achieved = dom["flops_per_tile"] * BATCH / avg_s / 1e12
             roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_is": "static: read from the committed profiles/ file named in traffic_detail (rocprofv3 --pmc passes of "
+                                  "the builder's run of this command), NOT measured in this run",
                     "traffic_detail": traffic_detail,
                     "flop_per_launch": dom["flops_per_tile"] * BATCH,
                     "avg_launch_ms": round(avg_s * 1e3, 4),
@@ -409,6 +427,10 @@ def run_rank(args):
         }
         if host is not None:
             out["host_pipeline"] = host
+        if real is not None:
+            out["real_crops"] = real
+        if cpus is not None:
+            out["rank0_cpus"] = len(cpus)
         if not args.dry_run:
             out["parity"] = parity_vs_golden(mask[0, :4].cpu().numpy())
             if n == 1 and not args.no_cpu_baseline:

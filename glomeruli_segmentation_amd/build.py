@@ -5,7 +5,7 @@
 The .so is git-ignored but travels to the GPU box with the working tree.  hipcc cross-compiles
 gfx950 code objects without a GPU.  `--out` + extra flags build an experiment variant of the same
 sources (e.g. `--out variants_so/libglomseg_nofuse.so -- -DCFG_FUSE_L3=0`), selected at run time
-with GLOMSEG_LIB; `-DGS_DIAG` adds the timing / stamp variants the product build leaves out.
+with GLOMSEG_EXPERIMENT=1 GLOMSEG_LIB=...; `-DGS_DIAG` adds the timing / stamp variants the product build leaves out.
 """
 import os
 import subprocess
@@ -15,10 +15,11 @@ import tempfile
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libglomseg.so")
-SOURCES = ["espnet.hip", "detect_ops.hip", "detector.hip", "contours.cpp"]
-HEADERS = ["gs_internal.h", "conv_mfma.h", "dec_tail.h", "espnet_kernels.h", os.path.join("..", "..", "include", "glomseg.h")]
+SOURCES = ["espnet.hip", "crops.hip", "detect_ops.hip", "detector.hip", "contours.cpp"]
+HEADERS = ["gs_internal.h", "conv_mfma.h", "dec_tail.h", "espnet_kernels.h", "crop_sample.h", "host_copy.h",
+           os.path.join("..", "..", "include", "glomseg.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
-         "-Wno-unused-value"] + os.environ.get("GS_EXTRA_HIPCC_FLAGS", "").split()
+         "-Wno-unused-value"]      # extra flags only through the command line (`-- ...` with --out): no environment knob
 
 
 def _sources():

@@ -69,6 +69,12 @@ class SlideCompositor:
             sx, sy = reference_window_luts(slide_width, slide_height)
             self.luts = (torch.from_numpy(sx).to(self.device), torch.from_numpy(sy).to(self.device))
 
+    def paste_target(self):
+        """the map as the _lib.PasteTarget the batched crop entries take (gs_espnet_segment_crops*): they paste a whole batch
+        of crops per launch, with the same result as paste() per crop"""
+        from .engine import paste_target
+        return paste_target(self.map, self.ds, self.luts)
+
     def paste(self, crop_mask, x1, y1):
         """crop_mask: uint8 [h,w] (level-0 resolution) on the GPU or host; (x1,y1) level-0 origin of the box."""
         if not isinstance(crop_mask, torch.Tensor):

@@ -35,6 +35,12 @@ struct DecTailArgs {
     float *ff;            // optional: the CBR output (stage "conv") as a gs::Act
     long long ff_sn;
     int ff_sc, ff_pitch, ff_off;
+    // ensemble (BASELINE cfg 5, definition in DESIGN.md): prob [N][CLS][2*H1][2*W1] accumulates ens_w * softmax(logits) over the
+    // member models.  ens_mode 1: first member (store), 2: a middle member (add), 3: the last member (add, then argmax of the
+    // sum -> mask + counts; nothing is written back), 4: a single member (softmax -> argmax, prob untouched).  0: no ensemble.
+    float *prob;
+    int ens_mode;
+    float ens_w;
     int N, H1, W1;
     int xbase, nstrips;   // this launch covers strips of 16P-2 output columns starting at column xbase
     int bands, R, k3;     // bands of R = 3*k3 + 2 output rows
@@ -67,8 +73,9 @@ struct DecTailGeom {
 
 // (everything is local arrays + generic lambdas with compile-time indices: kept in one function body so that the
 // accumulators, the operand ring and the weights stay in registers)
-// DBG: also write the logits and the half-resolution CBR output (tests, ensemble).  A separate instantiation, so that the
-// per-lane store addresses of those outputs do not sit in registers of the mask-only kernel.
+// MODE 1 (DBG): also write the logits and the half-resolution CBR output (tests).  MODE 2 (ENS): the logits go through a softmax
+// into the ensemble's probability accumulator instead of straight to the argmax.  Separate instantiations, so that the
+// per-lane addresses of those outputs do not sit in registers of the mask-only kernel (MODE 0).
 // timing-only ablations (results wrong by construction), -DGS_DIAG builds only
 #if defined(GS_DIAG) && defined(DT_X_NOLOAD)
 constexpr bool kDtNoLoad = true;
@@ -86,9 +93,10 @@ constexpr bool kDtNoEpi = false;
 #ifndef DT_MAIN_WAVES
 #define DT_MAIN_WAVES 8
 #endif
-template <int CLS, int NRUN, bool DBG, int WAVES>
+template <int CLS, int NRUN, int MODE, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs a)
 {
+    constexpr bool DBG = MODE == 1, ENS = MODE == 2;
     using DT = DecTailGeom<CLS, NRUN>;
     constexpr int P = DT::P, NG = DT::NG, TS = DT::TS, XS = DT::XS, IMGS = DT::IMGS, CW = DT::CW, LPI = DT::LPI;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -281,23 +289,82 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
 #pragma unroll
                             for (int i = 0; i < CLS; ++i)
                                 t = fmaf(f[q][i], w5[i], t);
-                            if (DBG)
+                            if (DBG || ENS)
                                 lg[o][2 * q + dx] = t;
-                            if (o == 0 || t > best[q]) {   // strict '>': the first maximum wins (torch.max semantics)
+                            if (!ENS && (o == 0 || t > best[q])) {   // strict '>': the first maximum wins (torch.max semantics)
                                 best[q] = t;
                                 bi[q] = o;
                             }
                         }
                     }
+                    if (!ENS) {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        mbytes |= (unsigned)bi[q] << (8 * (2 * q + dx));
-                        if (ok && yo >= yb)
-                            counts += 1ull << (12 * bi[q]);
+                        for (int q = 0; q < 2; ++q) {
+                            mbytes |= (unsigned)bi[q] << (8 * (2 * q + dx));
+                            if (ok && yo >= yb)
+                                counts += 1ull << (12 * bi[q]);
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (ok) {
+                if (ENS) {
+                    // prob (+)= ens_w * softmax(logits), in the arithmetic of the two-kernel form this replaces (max-shifted
+                    // expf, one division per class); the last member goes on to the first-max argmax of the sum
+                    float pr[CLS][4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float mx = -3.4e38f;
+#pragma unroll
+                        for (int o = 0; o < CLS; ++o)
+                            mx = fmaxf(mx, lg[o][c]);
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int o = 0; o < CLS; ++o) {
+                            pr[o][c] = expf(lg[o][c] - mx);
+                            sum += pr[o][c];
+                        }
+#pragma unroll
+                        for (int o = 0; o < CLS; ++o)
+                            pr[o][c] = pr[o][c] / sum * a.ens_w;
+                    }
+                    // (yo >= yb: the rows a shifted last band shares with its neighbour belong to the neighbour -- a mask store may
+                    // be repeated, an accumulation may not)
+                    if (ok && yo >= yb) {
+                        if (a.ens_mode == 2 || a.ens_mode == 3) {
+#pragma unroll
+                            for (int o = 0; o < CLS; ++o) {
+                                const float4 old = *reinterpret_cast<const float4 *>(
+                                    a.prob + (((long long)n * CLS + o) * H + 2 * yo + dy) * W + 2 * x);
+                                pr[o][0] = old.x + pr[o][0];
+                                pr[o][1] = old.y + pr[o][1];
+                                pr[o][2] = old.z + pr[o][2];
+                                pr[o][3] = old.w + pr[o][3];
+                            }
+                        }
+                        if (a.ens_mode == 1 || a.ens_mode == 2) {
+#pragma unroll
+                            for (int o = 0; o < CLS; ++o)
+                                *reinterpret_cast<float4 *>(a.prob + (((long long)n * CLS + o) * H + 2 * yo + dy) * W + 2 * x) =
+                                    make_float4(pr[o][0], pr[o][1], pr[o][2], pr[o][3]);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                float best = pr[0][c];
+                                int bi = 0;
+#pragma unroll
+                                for (int o = 1; o < CLS; ++o)
+                                    if (pr[o][c] > best) {
+                                        best = pr[o][c];
+                                        bi = o;
+                                    }
+                                mbytes |= (unsigned)bi << (8 * c);
+                                counts += 1ull << (12 * bi);
+                            }
+                            if (a.mask)
+                                __builtin_amdgcn_raw_buffer_store_b32(mbytes, rmask, n * (H * W) + 2 * x, (2 * yo + dy) * W, 2 /* nt */);
+                        }
+                    }
+                } else if (ok) {
                     if (a.mask)   // (uniform) one 32-bit offset per lane, the row in the scalar offset
                         __builtin_amdgcn_raw_buffer_store_b32(mbytes, rmask, n * (H * W) + 2 * x, (2 * yo + dy) * W, 2 /* nt */);
                     if (DBG && a.logits) {
@@ -376,6 +443,8 @@ static gs_status launch_dec_tail_p(DecTailArgs a, int num_cus, hipStream_t strea
     int k3 = (cdiv(a.H1, bands) - 2 + 2) / 3;   // smallest k with 3k+2 >= H1/bands
     if (k3 < 0) k3 = 0;
     while (k3 > 0 && 3 * k3 + 2 > a.H1) --k3;   // a band never exceeds the image (H1 >= 4; k3 == 0 gives two-row bands)
+    // a lane counts 8 pixels per band row into 12-bit fields: R <= 509 rows keeps an all-one-class band (4072) below 4096
+    if (k3 > 169) k3 = 169;
     a.k3 = k3;
     a.R = 3 * k3 + 2;
     a.bands = cdiv(a.H1, a.R);
@@ -385,12 +454,13 @@ static gs_status launch_dec_tail_p(DecTailArgs a, int num_cus, hipStream_t strea
         return GS_ERR_UNSUPPORTED;
     }
     const size_t lds_bytes = (size_t)(128 + WAVES * 16 * DT::TS) * sizeof(float);
-    auto kern = a.logits ? dec_tail_kernel<5, NRUN, true, WAVES> : dec_tail_kernel<5, NRUN, false, WAVES>;
+    const int mode = a.ens_mode ? 2 : a.logits ? 1 : 0;
+    auto kern = mode == 2 ? dec_tail_kernel<5, NRUN, 2, WAVES> : mode == 1 ? dec_tail_kernel<5, NRUN, 1, WAVES> : dec_tail_kernel<5, NRUN, 0, WAVES>;
     static std::mutex mu;
     static std::map<int, bool> attr_done;
     int dev = 0;
     GS_HIP(hipGetDevice(&dev));
-    dev = dev * 2 + (a.logits ? 1 : 0);   // (device, instantiation)
+    dev = dev * 3 + mode;   // (device, instantiation)
     {
         std::lock_guard<std::mutex> lock(mu);
         if (!attr_done[dev]) {

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "crop_sample.h"
 #include "gs_internal.h"
 
 namespace gs {
@@ -623,26 +624,7 @@ nms_scan_kernel(const unsigned long long *mask, const int *order, const int *n_v
 }
 
 // ---------------------------------------------------------------------------------------------
-// Crop stage.  cv2.resize INTER_LINEAR on a float image: fx = (float)((dx+0.5)*scale-0.5),
-// sx = floor(fx), fx -= sx, clamped at both borders; horizontal pass first, then vertical.
-__device__ __forceinline__ void linear_tap(int d, double scale, int n, int &i0, int &i1, float &w1)
-{
-    float f = (float)(((double)d + 0.5) * scale - 0.5);
-    int s = (int)floorf(f);
-    f -= (float)s;
-    if (s < 0) {
-        s = 0;
-        f = 0.0f;
-    }
-    if (s >= n - 1) {
-        s = n - 1;
-        f = 0.0f;
-    }
-    i0 = s;
-    i1 = s + 1 < n ? s + 1 : n - 1;
-    w1 = f;
-}
-
+// Crop stage, one crop per launch; the sampling rules are in crop_sample.h (shared with crops.hip)
 struct CropArgs {
     const unsigned char *src;
     int h, w, oh, ow;
@@ -658,21 +640,11 @@ __global__ void __launch_bounds__(256) crop_preprocess_kernel(const CropArgs a)
     const int ox = idx % a.ow, oy = idx / a.ow;
     int x0, x1, y0, y1;
     float wx, wy;
-    // OpenCV's own expression: scale = 1. / inv_scale with inv_scale = (double)dst / src
-    linear_tap(ox, 1.0 / ((double)a.ow / (double)a.w), a.w, x0, x1, wx);
-    linear_tap(oy, 1.0 / ((double)a.oh / (double)a.h), a.h, y0, y1, wy);
+    linear_tap(ox, cv_inv_scale(a.ow, a.w), a.w, x0, x1, wx);
+    linear_tap(oy, cv_inv_scale(a.oh, a.h), a.h, y0, y1, wy);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        auto norm = [&](int y, int x) {
-            float v = (float)a.src[((long long)y * a.w + x) * 3 + c];
-            v = v - a.mean[c];
-            return v / a.std[c];
-        };
-        const float top = norm(y0, x0) * (1.0f - wx) + norm(y0, x1) * wx;
-        const float bot = norm(y1, x0) * (1.0f - wx) + norm(y1, x1) * wx;
-        const float v = top * (1.0f - wy) + bot * wy;
-        a.out[((long long)c * a.oh + oy) * a.ow + ox] = v / 255.0f;
-    }
+    for (int c = 0; c < 3; ++c)
+        a.out[((long long)c * a.oh + oy) * a.ow + ox] = crop_sample(a.src, a.w, c, x0, x1, y0, y1, wx, wy, a.mean[c], a.std[c]);
 }
 
 __global__ void __launch_bounds__(256)
@@ -682,11 +654,7 @@ mask_nearest_kernel(const unsigned char *src, int h, int w, int oh, int ow, unsi
     if (idx >= oh * ow)
         return;
     const int ox = idx % ow, oy = idx / ow;
-    // OpenCV resizeNN: ifx = 1. / fx with fx = (double)dst / src; sx = min(cvFloor(x * ifx), src - 1)
-    int sx = (int)floor((double)ox * (1.0 / ((double)ow / (double)w)));
-    int sy = (int)floor((double)oy * (1.0 / ((double)oh / (double)h)));
-    sx = sx < w - 1 ? sx : w - 1;
-    sy = sy < h - 1 ? sy : h - 1;
+    const int sx = nearest_src(ox, cv_inv_scale(ow, w), w), sy = nearest_src(oy, cv_inv_scale(oh, h), h);
     out[idx] = src[(long long)sy * w + sx];
 }
 

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "gs_internal.h"
+#include "host_copy.h"
 
 namespace gs {
 
@@ -582,7 +583,32 @@ struct Detector {
     float rpn_iou = 0.7f, det_iou = 0.6f, det_score = 0.0f;
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    // host pipeline (gs_detector_detect_host): three slots of pinned + device staging, kept across calls
+    struct Slot {
+        unsigned char *hin = nullptr, *din = nullptr;
+        float *hres = nullptr, *dres = nullptr;   // [boxes n*D*4 | scores n*D | classes n*D | num n]
+        hipEvent_t up = nullptr, down = nullptr;
+        int first = -1, count = 0;
+    } sl[3];
+    size_t pipe_in_bytes = 0;
+    int pipe_batch = 0;
+    hipStream_t pipe_h2d = nullptr, pipe_compute = nullptr;
 };
+
+static void free_det_pipeline(Detector &d)
+{
+    for (auto &s : d.sl) {
+        if (s.hin) hipHostFree(s.hin);
+        if (s.hres) hipHostFree(s.hres);
+        if (s.din) hipFree(s.din);
+        if (s.dres) hipFree(s.dres);
+        if (s.up) hipEventDestroy(s.up);
+        if (s.down) hipEventDestroy(s.down);
+        s = Detector::Slot();
+    }
+    d.pipe_in_bytes = 0;
+    d.pipe_batch = 0;
+}
 
 static inline unsigned nblk(long long items) { return (unsigned)((items + 255) / 256); }
 
@@ -669,6 +695,9 @@ void gs_detector_destroy(gs_detector *h)
     if (!h)
         return;
     hipDeviceSynchronize();
+    free_det_pipeline(h->d);
+    if (h->d.pipe_h2d) hipStreamDestroy(h->d.pipe_h2d);
+    if (h->d.pipe_compute) hipStreamDestroy(h->d.pipe_compute);
     if (h->d.ws) hipFree(h->d.ws);
     if (h->d.dblob) hipFree(h->d.dblob);
     delete h;
@@ -793,6 +822,100 @@ gs_status gs_detector_forward(gs_detector *h, const uint8_t *images_rgb, int n, 
     if (dbg_head) GS_HIP(hipMemcpyAsync(dbg_head, F(pH), (size_t)n * P * 6 * 4, hipMemcpyDeviceToDevice, s));
 #undef DET_TRY
     return GS_OK;
+}
+
+gs_status gs_detector_detect_host(gs_detector *h, const uint8_t *const *windows, int n, int height, int width, int batch, float *boxes,
+                                  float *scores, float *classes, float *num)
+{
+    GS_REQUIRE(h && windows && boxes && scores && classes && num, "gs_detector_detect_host: null argument");
+    GS_REQUIRE(n > 0 && batch > 0, "n and batch must be positive");
+    for (int i = 0; i < n; ++i)
+        GS_REQUIRE(windows[i], "window %d is a null pointer", i);
+    if (batch > n) batch = n;
+    Detector &d = h->d;
+    constexpr int NSLOT = 3, D = DET_MAX_DET;
+    const size_t in_b = (size_t)height * width * 3;
+    const size_t res_f = (size_t)batch * (D * 6 + 1);   // floats per slot
+    gs_status rc = GS_OK;
+    auto fail = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == GS_OK) {
+            set_error("%s failed: %s", what, hipGetErrorString(e));
+            rc = GS_ERR_HIP;
+        }
+        return e != hipSuccess;
+    };
+    if (!d.pipe_h2d) {
+        int lo = 0, hi = 0;
+        fail(hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange");
+        fail(hipStreamCreateWithPriority(&d.pipe_h2d, hipStreamNonBlocking, hi), "hipStreamCreate");
+        fail(hipStreamCreateWithPriority(&d.pipe_compute, hipStreamNonBlocking, lo), "hipStreamCreate");
+    }
+    if (d.pipe_in_bytes < in_b * batch || d.pipe_batch < batch) {
+        fail(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        free_det_pipeline(d);
+        for (auto &s : d.sl) {
+            fail(hipHostMalloc(reinterpret_cast<void **>(&s.hin), in_b * batch, hipHostMallocDefault), "hipHostMalloc");
+            fail(hipHostMalloc(reinterpret_cast<void **>(&s.hres), res_f * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
+            fail(hipMalloc(reinterpret_cast<void **>(&s.din), in_b * batch), "hipMalloc");
+            fail(hipMalloc(reinterpret_cast<void **>(&s.dres), res_f * sizeof(float)), "hipMalloc");
+            fail(hipEventCreateWithFlags(&s.up, hipEventDisableTiming), "hipEventCreate");
+            fail(hipEventCreateWithFlags(&s.down, hipEventDisableTiming), "hipEventCreate");
+        }
+        if (rc != GS_OK) {
+            free_det_pipeline(d);
+            return rc;
+        }
+        d.pipe_in_bytes = in_b * batch;
+        d.pipe_batch = batch;
+    }
+    for (auto &s : d.sl)
+        s.first = -1;
+    const int pb = d.pipe_batch;   // the slot layout follows the batch the buffers were made for
+    auto drain = [&](Detector::Slot &s) {
+        if (s.first < 0 || rc != GS_OK)
+            return;
+        if (fail(hipEventSynchronize(s.down), "hipEventSynchronize")) return;
+        const float *r = s.hres;
+        std::memcpy(boxes + (size_t)s.first * D * 4, r, sizeof(float) * s.count * D * 4);
+        std::memcpy(scores + (size_t)s.first * D, r + (size_t)pb * D * 4, sizeof(float) * s.count * D);
+        std::memcpy(classes + (size_t)s.first * D, r + (size_t)pb * D * 5, sizeof(float) * s.count * D);
+        std::memcpy(num + s.first, r + (size_t)pb * D * 6, sizeof(float) * s.count);
+        s.first = -1;
+    };
+    int slot = 0;
+    for (int first = 0; first < n && rc == GS_OK; first += batch, slot = (slot + 1) % NSLOT) {
+        Detector::Slot &s = d.sl[slot];
+        drain(s);
+        if (rc != GS_OK) break;
+        const int cnt = n - first < batch ? n - first : batch;
+        bool direct = true;
+        for (int j = 0; j < cnt; ++j)
+            direct = direct && host_is_pinned(windows[first + j]);
+        if (direct) {
+            for (int j = 0; j < cnt && rc == GS_OK; ++j)
+                fail(hipMemcpyAsync(s.din + (size_t)j * in_b, windows[first + j], in_b, hipMemcpyHostToDevice, d.pipe_h2d), "H2D copy");
+        } else {
+            parallel_jobs(cnt, 4, [&](int j) { std::memcpy(s.hin + (size_t)j * in_b, windows[first + j], in_b); });
+            fail(hipMemcpyAsync(s.din, s.hin, in_b * cnt, hipMemcpyHostToDevice, d.pipe_h2d), "H2D copy");
+        }
+        if (rc != GS_OK) break;
+        fail(hipEventRecord(s.up, d.pipe_h2d), "hipEventRecord");
+        fail(hipStreamWaitEvent(d.pipe_compute, s.up, 0), "hipStreamWaitEvent");
+        float *r = s.dres;
+        gs_status st2 = gs_detector_forward(h, s.din, cnt, height, width, r, r + (size_t)pb * D * 4, r + (size_t)pb * D * 5,
+                                            r + (size_t)pb * D * 6, nullptr, nullptr, nullptr, nullptr, d.pipe_compute);
+        if (st2 != GS_OK) { rc = st2; break; }
+        const size_t rb = (size_t)pb * (D * 6 + 1) * sizeof(float);
+        fail(hipMemcpy2DAsync(s.hres, rb, s.dres, rb, rb, 1, hipMemcpyDeviceToHost, d.pipe_compute), "D2H copy");
+        fail(hipEventRecord(s.down, d.pipe_compute), "hipEventRecord");
+        s.first = first;
+        s.count = cnt;
+    }
+    for (int k = 0; k < NSLOT; ++k)
+        drain(d.sl[(slot + k) % NSLOT]);
+    if (rc != GS_OK)
+        hipDeviceSynchronize();
+    return rc;
 }
 
 }  // extern "C"

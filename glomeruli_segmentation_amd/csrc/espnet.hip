@@ -14,6 +14,7 @@
 #include "conv_mfma.h"
 #include "dec_tail.h"
 #include "espnet_kernels.h"
+#include "host_copy.h"
 
 namespace gs {
 
@@ -406,6 +407,9 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
         return GS_ERR_NOMEM;
     }
     GS_HIP(hipMemset(ws, 0, total));   // halos and padded channel planes are zero from here on
+    // (the fill runs on the NULL stream, which non-blocking streams -- the host pipelines' own, torch's side streams -- do not
+    // wait for: a forward launched on one of them right after this call must not meet the fill still in flight)
+    GS_HIP(hipDeviceSynchronize());
     size_t at = 0;
     for (Act *a : all) {
         a->base = reinterpret_cast<float *>(static_cast<char *>(ws) + at);
@@ -557,7 +561,8 @@ static gs_status diag_l3_variants(Model *m, ConvArgs ca, int i, hipStream_t s)
 
 template <int CLS>
 static gs_status forward_impl(Model *m, const void *in, int in_format, int n, int H, int W, const float *mean,
-                              const float *stdv, float *logits, uint8_t *mask, unsigned long long *hist, hipStream_t s)
+                              const float *stdv, float *logits, uint8_t *mask, unsigned long long *hist, hipStream_t s,
+                              float *prob = nullptr, int ens_mode = 0, float ens_w = 1.0f)
 {
     const float *wb = m->dblob;
     Launcher L{m, s, GS_OK, n};
@@ -588,7 +593,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         a.N = n;
         a.H = H;
         a.W = W;
-        if (hist && !m->encoder_only) {   // zeroed by the first kernel of the forward; the last one adds into it
+        if (hist && !m->encoder_only && (ens_mode == 0 || ens_mode >= 3)) {   // zeroed by the first kernel of the forward; the last one adds into it
             a.hist_zero = hist;
             a.hist_count = n * CLS;
         }
@@ -843,7 +848,10 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         a.wpack = wb + m->wtail;
         a.logits = logits;
         a.mask = mask;
-        a.hist = hist;
+        a.hist = (ens_mode == 1 || ens_mode == 2) ? nullptr : hist;   // only the last member of an ensemble counts
+        a.prob = prob;
+        a.ens_mode = ens_mode;
+        a.ens_w = ens_w;
         if (logits) {   // debug / test path: the half-resolution CBR output is kept as stage "conv"
             a.ff = m->ff.base;
             a.ff_sn = m->ff.sn;
@@ -859,31 +867,6 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     if (logits)
         set_stage("conv", m->ff, CLS);
     return L.st;
-}
-
-// memcpy of a staging buffer on a few threads: one core copies ~10 GB/s, and a 50 MB batch of pageable tiles copied by the
-// enqueueing thread alone (4-5 ms) is slower than the GPU's 2.9 ms per batch
-static void parallel_memcpy(void *dst, const void *src, size_t bytes)
-{
-    constexpr size_t kMinPerThread = 4u << 20;
-    unsigned nt = (unsigned)(bytes / kMinPerThread);
-    const unsigned hw = std::thread::hardware_concurrency();
-    if (nt > 4) nt = 4;
-    if (hw && nt > hw) nt = hw;
-    if (nt <= 1) {
-        std::memcpy(dst, src, bytes);
-        return;
-    }
-    const size_t chunk = (bytes / nt + 63) / 64 * 64;
-    std::vector<std::thread> th;
-    for (unsigned i = 1; i < nt; ++i) {
-        const size_t lo = i * chunk, hi = i + 1 == nt ? bytes : (i + 1) * chunk;
-        if (lo < hi)
-            th.emplace_back([=] { std::memcpy(static_cast<char *>(dst) + lo, static_cast<const char *>(src) + lo, hi - lo); });
-    }
-    std::memcpy(dst, src, chunk < bytes ? chunk : bytes);
-    for (auto &t : th)
-        t.join();
 }
 
 static void free_pipeline(Model &m)
@@ -912,7 +895,15 @@ using namespace gs;
 extern "C" {
 
 const char *gs_last_error(void) { return g_err.c_str(); }
-int gs_abi_version(void) { return 2; }   // 2: lanes, block hook, detector, compositor LUT
+int gs_abi_version(void) { return 3; }   // 2: lanes, block hook, detector, compositor LUT; 3: batched crop entries, detector host entry, build flags
+int gs_build_flags(void)
+{
+#ifdef GS_DIAG
+    return GS_BUILD_DIAG;
+#else
+    return 0;
+#endif
+}
 
 // A handle = the model (weights + lane-0 workspace) plus optional extra LANES: shallow copies of the model that share
 // the device weight blob and own a workspace of their own, so that two batches can be in flight on two HIP streams
@@ -922,8 +913,55 @@ struct gs_espnet {
     Model m;
     std::vector<std::unique_ptr<Model>> lanes;   // lane k >= 1 is lanes[k - 1]
     hipStream_t pipe_compute2 = nullptr;         // gs_espnet_segment_host: the second of its two streams (odd batches)
+    gs::CropPipe *crop_pipe = nullptr;           // gs_espnet_segment_crops*: staging state (csrc/crops.hip)
     Model &lane(int k) { return k == 0 ? m : *lanes[k - 1]; }
 };
+
+}  // extern "C"
+
+namespace gs {
+CropPipe *&espnet_crop_pipe(gs_espnet *h) { return h->crop_pipe; }
+int espnet_device(gs_espnet *h) { return h->m.device; }
+int espnet_is_full_net(gs_espnet *h) { return h->m.encoder_only ? 0 : 1; }
+int espnet_lanes(gs_espnet *h) { return 1 + (int)h->lanes.size(); }
+// the ensemble's fp32 probability accumulator [n][5][height][width], owned by the first member's handle
+gs_status ensemble_scratch(gs_espnet *h, int n, int height, int width, float **prob)
+{
+    Model &m0 = h->m;
+    const size_t need = (size_t)n * 5 * height * width * sizeof(float);
+    if (m0.prob_bytes < need) {
+        if (m0.prob) {
+            GS_HIP(hipDeviceSynchronize());
+            GS_HIP(hipFree(m0.prob));
+        }
+        m0.prob = nullptr;
+        m0.prob_bytes = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&m0.prob), need) != hipSuccess) {
+            set_error("ensemble scratch allocation of %zu bytes failed", need);
+            return GS_ERR_NOMEM;
+        }
+        m0.prob_bytes = need;
+    }
+    *prob = m0.prob;
+    return GS_OK;
+}
+// the forward with every option (ensemble accumulator included); arguments are the caller's responsibility beyond the
+// checks of gs_espnet_forward_lane
+gs_status espnet_forward_ex(gs_espnet *h, int lane, const void *in, int in_format, int n, int height, int width, const float *mean,
+                            const float *stdv, float *logits, uint8_t *mask, unsigned long long *hist, float *prob, int ens_mode,
+                            float ens_w, hipStream_t s)
+{
+    GS_REQUIRE(h && in, "forward: null handle or input");
+    GS_REQUIRE(lane >= 0 && lane <= (int)h->lanes.size(), "lane %d does not exist (gs_espnet_set_lanes)", lane);
+    Model &m = h->lane(lane);
+    GS_REQUIRE(!m.encoder_only || ens_mode == 0, "an ESPNet-C handle cannot be an ensemble member");
+    gs_status st = layout_workspace(&m, n, height, width);
+    if (st != GS_OK) return st;
+    return forward_impl<5>(&m, in, in_format, n, height, width, mean, stdv, logits, mask, hist, s, prob, ens_mode, ens_w);
+}
+}  // namespace gs
+
+extern "C" {
 
 gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_layers, int classes, int p, int q,
                            int encoder_only, gs_espnet **out)
@@ -1087,6 +1125,7 @@ void gs_espnet_destroy(gs_espnet *h)
         hipEventDestroy(ev.b);
     }
     free_pipeline(h->m);
+    crop_pipe_destroy(h->crop_pipe);
     if (h->m.pipe_compute) hipStreamDestroy(h->m.pipe_compute);
     if (h->m.pipe_h2d) hipStreamDestroy(h->m.pipe_h2d);
     if (h->pipe_compute2) hipStreamDestroy(h->pipe_compute2);
@@ -1319,31 +1358,23 @@ gs_status gs_espnet_ensemble_forward(gs_espnet *const *models, int n_models, con
     gs_status st = check_shape(n, height, width);
     if (st != GS_OK) return st;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    Model &m0 = models[0]->m;
-    const size_t need = (size_t)n * 5 * height * width * sizeof(float) * 2;   // [logits | prob]
-    if (m0.prob_bytes < need) {
-        if (m0.prob) GS_HIP(hipFree(m0.prob));
-        m0.prob = nullptr;
-        m0.prob_bytes = 0;
-        if (hipMalloc(reinterpret_cast<void **>(&m0.prob), need) != hipSuccess) {
-            set_error("ensemble scratch allocation of %zu bytes failed", need);
-            return GS_ERR_NOMEM;
-        }
-        m0.prob_bytes = need;
-    }
-    float *lg = m0.prob, *prob = m0.prob + (size_t)n * 5 * height * width;
-    const long long npix = (long long)height * width;
     for (int k = 0; k < n_models; ++k) {
         GS_REQUIRE(models[k] && !models[k]->m.encoder_only, "ensemble member %d is not a full ESPNet", k);
-        st = gs_espnet_forward(models[k], in_u8, GS_IN_U8_BGR_NHWC, n, height, width, means + 3 * k, stds + 3 * k, lg,
-                               nullptr, nullptr, hip_stream);
-        if (st != GS_OK) return st;
-        hipLaunchKernelGGL(softmax_accum_kernel<5>, dim3(blocks_for(npix * n)), dim3(256), 0, s, lg, prob, npix, npix * n,
-                           1.0f / (float)n_models, k == 0 ? 1 : 0);
+        for (int i = 0; i < 3; ++i)
+            GS_REQUIRE(stds[3 * k + i] != 0.0f, "ensemble member %d: std[%d] is zero", k, i);
     }
-    if (hist) GS_HIP(hipMemsetAsync(hist, 0, sizeof(unsigned long long) * n * 5, s));
-    hipLaunchKernelGGL(argmax_hist_kernel<5>, dim3(blocks_for(npix), n), dim3(256), 0, s, prob, mask, hist, (int)npix);
-    GS_HIP(hipGetLastError());
+    float *prob = nullptr;
+    st = ensemble_scratch(models[0], n, height, width, &prob);
+    if (st != GS_OK) return st;
+    // Every member's decoder tail turns its five logits into probabilities in registers and adds 1/K of them into ONE fp32
+    // accumulator (first member stores, middle members add, the last adds and goes on to the argmax and the counts): the
+    // logits are never written, and the accumulator is read K-1 and written K-1 times.
+    for (int k = 0; k < n_models; ++k) {
+        const int mode = n_models == 1 ? 4 : k == 0 ? 1 : k == n_models - 1 ? 3 : 2;
+        st = espnet_forward_ex(models[k], 0, in_u8, GS_IN_U8_BGR_NHWC, n, height, width, means + 3 * k, stds + 3 * k, nullptr, mask,
+                               hist, prob, mode, 1.0f / (float)n_models, s);
+        if (st != GS_OK) return st;
+    }
     return GS_OK;
 }
 
@@ -1361,15 +1392,7 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
     const int nl = h->lanes.empty() ? 1 : 2;   // batches alternate between (at most) two lanes, each on its own compute stream
     // caller buffers that are already page-locked (hipHostMalloc / hipHostRegister) are DMA'd in place;
     // pageable ones are staged through the pinned slot buffers with a host memcpy
-    auto is_pinned = [](const void *p) {
-        hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        return at.type == hipMemoryTypeHost;
-    };
-    const bool in_pinned = is_pinned(tiles), out_pinned = is_pinned(masks) && (!hist || is_pinned(hist));
+    const bool in_pinned = host_is_pinned(tiles), out_pinned = host_is_pinned(masks) && (!hist || host_is_pinned(hist));
     Model &m = h->m;
     using Slot = Model::Slot;
     Slot *sl = m.sl;

@@ -544,64 +544,6 @@ __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
     }
 }
 
-// ensemble helpers (cfg 5): prob += softmax(logits) * w ; final argmax + counts
-template <int CLS>
-__global__ void __launch_bounds__(256) softmax_accum_kernel(const float *logits, float *prob, long long npix_per_img,
-                                                            long long total, float wgt, int first)
-{
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total)
-        return;
-    const long long n = idx / npix_per_img, p = idx % npix_per_img;
-    float v[CLS], mx = -3.4e38f;
-#pragma unroll
-    for (int k = 0; k < CLS; ++k) {
-        v[k] = logits[(n * CLS + k) * npix_per_img + p];
-        mx = fmaxf(mx, v[k]);
-    }
-    float sum = 0.0f;
-#pragma unroll
-    for (int k = 0; k < CLS; ++k) {
-        v[k] = expf(v[k] - mx);
-        sum += v[k];
-    }
-#pragma unroll
-    for (int k = 0; k < CLS; ++k) {
-        float *q = prob + (n * CLS + k) * npix_per_img + p;
-        const float add = v[k] / sum * wgt;
-        *q = first ? add : *q + add;
-    }
-}
-
-template <int CLS>
-__global__ void __launch_bounds__(256) argmax_hist_kernel(const float *prob, unsigned char *mask, unsigned long long *hist,
-                                                          int npix_per_img)
-{
-    __shared__ unsigned int lhist[CLS];
-    const int n = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (threadIdx.x < CLS)
-        lhist[threadIdx.x] = 0;
-    __syncthreads();
-    if (p < npix_per_img) {
-        float best = 0.0f;
-        int bi = 0;
-#pragma unroll
-        for (int k = 0; k < CLS; ++k) {
-            const float t = prob[((long long)n * CLS + k) * npix_per_img + p];
-            if (k == 0 || t > best) {
-                best = t;
-                bi = k;
-            }
-        }
-        mask[(long long)n * npix_per_img + p] = (unsigned char)bi;
-        atomicAdd(&lhist[bi], 1u);
-    }
-    __syncthreads();
-    if (hist && threadIdx.x < CLS && lhist[threadIdx.x])
-        atomicAdd(&hist[(long long)n * CLS + threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
-}
-
 // copy one image of a padded activation to a dense CHW buffer (debug / tests)
 __global__ void __launch_bounds__(256) unpad_kernel(const ActV t, int n, int C, float *dst)
 {

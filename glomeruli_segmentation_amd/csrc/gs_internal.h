@@ -59,4 +59,17 @@ bool conv2d_nhwc_can_pack4(int n, int h, int w, int cin, int kh, int kw, int cou
 void conv2d_nhwc_pack4(const float *w, int kh, int kw, int cin, int cout, float *dst);
 gs_status conv2d_nhwc_packed4(ConvNhwcArgs a, hipStream_t stream);
 
+
+// ---- espnet.hip internals that the crop pipeline (crops.hip) builds on
+struct CropPipe;                                   // staging state of gs_espnet_segment_crops*, owned by the handle
+CropPipe *&espnet_crop_pipe(gs_espnet *h);
+void crop_pipe_destroy(CropPipe *p);               // crops.hip; called by gs_espnet_destroy
+int espnet_device(gs_espnet *h);
+int espnet_is_full_net(gs_espnet *h);
+int espnet_lanes(gs_espnet *h);
+gs_status ensemble_scratch(gs_espnet *h, int n, int height, int width, float **prob);
+gs_status espnet_forward_ex(gs_espnet *h, int lane, const void *in, int in_format, int n, int height, int width, const float *mean,
+                            const float *stdv, float *logits, uint8_t *mask, unsigned long long *hist, float *prob, int ens_mode,
+                            float ens_w, hipStream_t s);
+
 }  // namespace gs

@@ -73,17 +73,20 @@ def plan_windows(width, height, mpp_x, mpp_y, downsample, window_um=None, overla
 def boxes_from_detector(boxes, scores, window_x, window_y, thresh=0.5):
     """Threshold + denormalise (:355-368).  Quirk kept: the first len(score >= thresh) boxes are
     taken by position, which equals selection by index only because detector outputs are sorted by
-    descending score."""
+    descending score.
+    The products are formed in float64: the reference runs on the NumPy 1.x of its TensorFlow-1.12 stack, where
+    `WINDOW_X * xmin` (Python int x float32 scalar) promotes to float64; under NumPy 2 the same expression stays in
+    float32 and int() of it can land one pixel away."""
     boxes = np.squeeze(np.asarray(boxes))
     score = np.squeeze(np.asarray(scores))
     boxes = boxes.reshape(-1, 4)
     score = score.reshape(-1)
     n = int(np.count_nonzero(score >= thresh))
-    out = []
-    for i in range(n):
-        ymin, xmin, ymax, xmax = boxes[i]
-        out.append([int(window_x * xmin), int(window_y * ymin), int(window_x * xmax), int(window_y * ymax), score[i]])
-    return out
+    if n == 0:
+        return []
+    b = boxes[:n].astype(np.float64)
+    px = np.stack([window_x * b[:, 1], window_y * b[:, 0], window_x * b[:, 3], window_y * b[:, 2]], 1).astype(np.int64)   # int(): towards zero
+    return [[x1, y1, x2, y2, sc] for (x1, y1, x2, y2), sc in zip(px.tolist(), score[:n])]
 
 
 def csv_rows(bs, x_start, y_start, downsample, site_name, specimen_id, file_name, now=None):
@@ -109,15 +112,22 @@ def scan_slide(read_region, detector, plan, conf_threshold, site_name, specimen_
     lo, hi = rank_range(len(wins), rank, world)
     rows = []
     mine = wins[lo:hi]
-    for s in range(0, len(mine), max(batch, 1)):
-        chunk = mine[s:s + max(batch, 1)]
+    # a detector with a host pipeline (FrcnnDetector.detect_host: pinned uploads one batch ahead of the forward) is handed
+    # several batches of windows per call; any other callable gets `batch` windows per call
+    host = getattr(detector, "detect_host", None) if batch > 1 else None
+    per_call = max(batch, 1) * (4 if host is not None else 1)
+    for s in range(0, len(mine), per_call):
+        chunk = mine[s:s + per_call]
         ims = []
         for i, j, xs, ys in chunk:
             im = np.asarray(read_region(xs, ys, plan.window_x, plan.window_y))
             if im.shape[-1] == 4:
                 im = im[:, :, :3]                        # drop alpha (:277-278)
             ims.append(im)
-        boxes, scores, classes, num = detector(np.stack(ims))
+        if host is not None:
+            boxes, scores, classes, num = host(ims, batch=batch)
+        else:
+            boxes, scores, classes, num = detector(np.stack(ims))
         boxes, scores = np.asarray(boxes), np.asarray(scores)
         for k, (i, j, xs, ys) in enumerate(chunk):
             bs = boxes_from_detector(boxes[k], scores[k], plan.window_x, plan.window_y, conf_threshold)

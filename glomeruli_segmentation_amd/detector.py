@@ -101,6 +101,37 @@ class FrcnnDetector:
                 out["num"].data_ptr(), dbg[0], dbg[1], dbg[2], dbg[3], ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return out
 
+    def detect_host(self, windows, batch=16):
+        """gs_detector_detect_host: a list of equal-size uint8 RGB [H,W,3] windows in host memory (numpy; pinned CPU tensors are
+        DMA'd in place) -> (boxes [n,D,4], scores [n,D], classes [n,D], num [n]) numpy.  Uploads run one batch ahead of the
+        forward on a stream of their own; pageable windows are staged into pinned memory by a few threads."""
+        n = len(windows)
+        keep, ptrs = [], (ctypes.c_void_p * n)()
+        h = w = None
+        for i, im in enumerate(windows):
+            if isinstance(im, torch.Tensor):
+                if im.is_cuda or im.dtype != torch.uint8 or not im.is_contiguous():
+                    raise ValueError("window %d: expected a contiguous uint8 CPU tensor" % i)
+                ptrs[i] = im.data_ptr()
+            else:
+                im = np.ascontiguousarray(im, dtype=np.uint8)
+                ptrs[i] = im.ctypes.data
+            if im.ndim != 3 or im.shape[2] != 3 or (h is not None and tuple(im.shape[:2]) != (h, w)):
+                raise ValueError("window %d: expected uint8 [H,W,3], every window of one size" % i)
+            h, w = int(im.shape[0]), int(im.shape[1])
+            keep.append(im)
+        d = self.max_det
+        boxes = np.empty((n, d, 4), dtype=np.float32)
+        scores = np.empty((n, d), dtype=np.float32)
+        classes = np.empty((n, d), dtype=np.float32)
+        num = np.empty((n,), dtype=np.float32)
+        torch.cuda.current_stream(self.device).synchronize()     # the pipeline runs on streams of its own
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gs_detector_detect_host(self.handle, ptrs, n, h, w, int(batch), boxes.ctypes.data_as(ctypes.c_void_p),
+                                                        scores.ctypes.data_as(ctypes.c_void_p), classes.ctypes.data_as(ctypes.c_void_p),
+                                                        num.ctypes.data_as(ctypes.c_void_p)))
+        return boxes, scores, classes, num
+
     def __call__(self, images):
         if not isinstance(images, torch.Tensor):
             images = torch.from_numpy(np.ascontiguousarray(images, dtype=np.uint8))

@@ -102,6 +102,14 @@ class EspnetEngine:
         for st in self._lane_streams.values():
             cur.wait_stream(st)
 
+    def quiesce(self):
+        """block until everything submitted for this handle -- on the current stream or on a lane's stream -- has finished.
+        The host pipelines (segment_host, segment_crops) run on streams of the library's own in workspaces 0 and 1 and
+        expect exactly that (include/glomseg.h)."""
+        for st in self._lane_streams.values():
+            st.synchronize()
+        torch.cuda.current_stream(self.device).synchronize()
+
     def close(self):
         if getattr(self, "handle", None):
             with torch.cuda.device(self.device):
@@ -157,6 +165,8 @@ class EspnetEngine:
         logits = torch.empty((n, self.classes, h, w), dtype=torch.float32, device=dev) if want_logits else None
         with torch.cuda.device(dev):
             if lane is None:
+                if 0 in self._lane_streams:      # workspace 0 may still be in use on lane 0's own stream
+                    torch.cuda.current_stream(dev).wait_stream(self._lane_streams[0])
                 k, sp = 0, _stream_ptr(dev)
             else:
                 st = self.lane_stream(lane)
@@ -174,6 +184,7 @@ class EspnetEngine:
     def segment_host(self, tiles, mean, std, batch=32, want_hist=True, out_masks=None, out_hist=None):
         """numpy uint8 [T,H,W,3] in host memory -> (masks [T,H,W], counts [T,classes]) through the
         pinned double-buffered H2D / compute / D2H pipeline of the library."""
+        self.quiesce()
         if isinstance(tiles, torch.Tensor):      # e.g. a pinned CPU tensor: DMA'd in place, no staging copy
             if tiles.is_cuda or tiles.dtype != torch.uint8 or not tiles.is_contiguous():
                 raise ValueError("expected a contiguous uint8 CPU tensor")
@@ -200,6 +211,39 @@ class EspnetEngine:
                 self.handle, tiles.ctypes.data_as(ctypes.c_void_p), t, h, w, _lib.fptr3(mean), _lib.fptr3(std), batch,
                 masks.ctypes.data_as(ctypes.c_void_p), hist.ctypes.data_as(ctypes.c_void_p) if want_hist else None))
         return masks, (hist.astype(np.int64) if want_hist else None)
+
+    def segment_crops(self, crops, mean, std, net_h=512, net_w=1024, batch=32, **kw):
+        """The loop of VisualizeResults_iou.py:100-156 over crops of ANY sizes (numpy uint8 BGR [h,w,3] each, or pinned CPU
+        tensors) through the library's batched pipeline; see segment_crops_host for the keywords and the result."""
+        return segment_crops_host([self], [(mean, std)], crops, net_h, net_w, batch, **kw)
+
+    def segment_crops_resident(self, packed_in, descs, mean, std, net_h=512, net_w=1024, want_net_maps=True, want_hist=True,
+                               packed_out=None, paste=None, lane=None):
+        """Device-resident form (gs_espnet_segment_crops): packed_in is a uint8 GPU tensor holding the crops at
+        descs[i].in_off, descs a list of _lib.CropDesc.  Returns (net_maps [n,net_h,net_w] | None, counts [n,5] | None);
+        crop-size maps are written into packed_out (uint8 GPU tensor) at descs[i].out_off when it is given."""
+        n = len(descs)
+        dev = packed_in.device
+        tab = (_lib.CropDesc * n)(*descs)
+        net = torch.empty((n, net_h, net_w), dtype=torch.uint8, device=dev) if want_net_maps else None
+        hist = torch.empty((n, self.classes), dtype=torch.int64, device=dev) if want_hist else None
+        with torch.cuda.device(dev):
+            if lane is None:
+                if 0 in self._lane_streams:
+                    torch.cuda.current_stream(dev).wait_stream(self._lane_streams[0])
+                k, sp = 0, _stream_ptr(dev)
+            else:
+                st = self.lane_stream(lane)
+                st.wait_stream(torch.cuda.current_stream(dev))
+                for t in (packed_in, packed_out, net, hist):
+                    if t is not None:
+                        t.record_stream(st)
+                k, sp = lane, ctypes.c_void_p(st.cuda_stream)
+            _lib.check(self.lib.gs_espnet_segment_crops(
+                self.handle, k, packed_in.data_ptr(), tab, n, _lib.fptr3(mean), _lib.fptr3(std), net_h, net_w,
+                net.data_ptr() if net is not None else None, packed_out.data_ptr() if packed_out is not None else None,
+                hist.data_ptr() if hist is not None else None, ctypes.byref(paste) if paste is not None else None, sp))
+        return net, hist
 
     # ------------------------------------------------------------------ test / bench hooks
     def read_stage(self, name, image=0):
@@ -257,6 +301,84 @@ def mask_resize_nearest(mask, out_h, out_w):
     with torch.cuda.device(mask.device):
         _lib.check(lib.gs_mask_resize_nearest(mask.data_ptr(), h, w, out_h, out_w, out.data_ptr(), _stream_ptr(mask.device)))
     return out
+
+
+def paste_target(slide_map, ds=8, luts=None):
+    """_lib.PasteTarget for a uint8 [map_h,map_w] GPU tensor (the 1/ds slide map of composite.SlideCompositor)."""
+    if slide_map.dtype != torch.uint8 or slide_map.dim() != 2 or not slide_map.is_cuda or not slide_map.is_contiguous():
+        raise ValueError("slide_map must be a contiguous uint8 [map_h,map_w] tensor on the GPU")
+    t = _lib.PasteTarget()
+    t.slide_map = slide_map.data_ptr()
+    t.map_h, t.map_w, t.ds = int(slide_map.shape[0]), int(slide_map.shape[1]), int(ds)
+    t.sx_lut = luts[0].data_ptr() if luts is not None else None
+    t.sy_lut = luts[1].data_ptr() if luts is not None else None
+    return t
+
+
+def segment_crops_host(engines, mean_stds, crops, net_h=512, net_w=1024, batch=32, want_masks=True, want_net_maps=False,
+                       want_hist=True, paste=None, origins=None):
+    """gs_espnet_segment_crops_host: crops of any sizes in host memory -> per-crop class maps at crop size.
+
+    engines: one EspnetEngine (the plain model) or several (the cfg-5 ensemble, each with its own (mean, std) in mean_stds).
+    crops: list of uint8 BGR [h,w,3] numpy arrays / CPU tensors (pinned ones are DMA'd in place).
+    paste: an _lib.PasteTarget (see paste_target) + origins [(x1, y1), ...]: the crops are also max-composited into the
+    slide map on the GPU.
+    Returns dict(masks=list of uint8 [h,w] numpy views of one pinned buffer | None, net_maps=uint8 [n,net_h,net_w] | None,
+    counts=int64 [n,5] counts of the crop-size maps | None).
+    """
+    lib = _lib.load()
+    n = len(crops)
+    if n == 0:
+        return {"masks": [] if want_masks else None, "net_maps": None, "counts": None}
+    keep = []      # keeps converted inputs alive for the duration of the call
+    ptrs = (ctypes.c_void_p * n)()
+    hs, ws = (ctypes.c_int * n)(), (ctypes.c_int * n)()
+    for i, c in enumerate(crops):
+        if isinstance(c, torch.Tensor):
+            if c.is_cuda or c.dtype != torch.uint8 or c.dim() != 3 or c.shape[2] != 3 or not c.is_contiguous():
+                raise ValueError("crop %d: expected a contiguous uint8 [h,w,3] CPU tensor" % i)
+            ptrs[i] = c.data_ptr()
+        else:
+            c = np.ascontiguousarray(c, dtype=np.uint8)
+            if c.ndim != 3 or c.shape[2] != 3:
+                raise ValueError("crop %d: expected uint8 [h,w,3]" % i)
+            ptrs[i] = c.ctypes.data
+        keep.append(c)
+        hs[i], ws[i] = int(c.shape[0]), int(c.shape[1])
+    eng0 = engines[0]
+    handles = (ctypes.c_void_p * len(engines))(*[e.handle for e in engines])
+    means = (ctypes.c_float * (3 * len(engines)))(*[float(v) for ms in mean_stds for v in ms[0]])
+    stds = (ctypes.c_float * (3 * len(engines)))(*[float(v) for ms in mean_stds for v in ms[1]])
+    out_ptrs, out_buf, offs = None, None, None
+    if want_masks:       # one pinned buffer for all maps: the library DMAs every map straight to its place
+        sizes = [int(hs[i]) * int(ws[i]) for i in range(n)]
+        offs = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([(s + 63) // 64 * 64 for s in sizes], out=offs[1:])
+        out_buf = torch.empty(int(offs[-1]), dtype=torch.uint8, pin_memory=True)
+        base = out_buf.data_ptr()
+        out_ptrs = (ctypes.c_void_p * n)(*[base + int(offs[i]) for i in range(n)])
+    net = torch.empty((n, net_h, net_w), dtype=torch.uint8, pin_memory=True) if want_net_maps else None
+    hist = torch.zeros((n, eng0.classes), dtype=torch.int64, pin_memory=True) if want_hist else None
+    x1 = y1 = None
+    if paste is not None:
+        if origins is None or len(origins) != n:
+            raise ValueError("paste needs one (x1, y1) level-0 origin per crop")
+        x1 = (ctypes.c_int * n)(*[int(o[0]) for o in origins])
+        y1 = (ctypes.c_int * n)(*[int(o[1]) for o in origins])
+    for e in engines:
+        e.quiesce()
+    with torch.cuda.device(eng0.device):
+        _lib.check(lib.gs_espnet_segment_crops_host(
+            handles, len(engines), ptrs, hs, ws, n, means, stds, net_h, net_w, batch, out_ptrs,
+            ctypes.c_void_p(net.data_ptr()) if net is not None else None,
+            ctypes.c_void_p(hist.data_ptr()) if hist is not None else None,
+            ctypes.byref(paste) if paste is not None else None, x1, y1))
+    masks = None
+    if want_masks:
+        flat = out_buf.numpy()
+        masks = [flat[int(offs[i]):int(offs[i]) + int(hs[i]) * int(ws[i])].reshape(int(hs[i]), int(ws[i])) for i in range(n)]
+    return {"masks": masks, "net_maps": net.numpy() if net is not None else None,
+            "counts": hist.numpy() if hist is not None else None}
 
 
 def ensemble_segment(engines, tiles_u8, mean_stds):

@@ -17,23 +17,15 @@ import torch
 
 from . import detect, merge
 from .composite import SlideCompositor
-from .engine import crop_preprocess, mask_resize_nearest
 from .shard import rank_range
 
 
-def segment_crops(engine, crops, mean, std, net_h, net_w, batch=32):
-    """crops: list of uint8 BGR [h,w,3] arrays of any size -> list of uint8 class maps [h,w] (GPU tensors)."""
-    out = []
-    dev = engine.device
-    for s in range(0, len(crops), batch):
-        chunk = crops[s:s + batch]
-        x = torch.empty((len(chunk), 3, net_h, net_w), dtype=torch.float32, device=dev)
-        for j, c in enumerate(chunk):
-            crop_preprocess(torch.from_numpy(np.ascontiguousarray(c)).to(dev), mean, std, net_h, net_w, out=x[j])
-        cls = engine.forward_logits(x).max(1)[1].byte()
-        for j, c in enumerate(chunk):
-            out.append(mask_resize_nearest(cls[j], c.shape[0], c.shape[1]))
-    return out
+def segment_crops(engine, crops, mean, std, net_h, net_w, batch=32, paste=None, origins=None, want_masks=True):
+    """crops: list of uint8 BGR [h,w,3] arrays of any size -> (list of uint8 class maps [h,w], counts int64 [n,5]) through
+    the library's batched crop pipeline (gs_espnet_segment_crops_host); with `paste` (+ origins) the maps are also
+    max-composited into the slide map on the GPU, in the same launches."""
+    r = engine.segment_crops(crops, mean, std, net_h, net_w, batch, want_masks=want_masks, paste=paste, origins=origins)
+    return r["masks"], r["counts"]
 
 
 def run_slide(engine, read_region, slide_w, slide_h, mpp_x, mpp_y, detector, mean, std, window_um=2000, overlap=0.1,
@@ -60,12 +52,14 @@ def run_slide(engine, read_region, slide_w, slide_h, mpp_x, mpp_y, detector, mea
     for b in boxes[lo:hi]:
         rgb = read_region(b[0], b[1], b[2] - b[0], b[3] - b[1], 1.0)               # make_seg_data.py:358
         crops.append(np.ascontiguousarray(rgb[:, :, ::-1]))                        # cv2.imread order: BGR
-    masks = segment_crops(engine, crops, mean, std, net_h, net_w, batch)
     comp = SlideCompositor(slide_w, slide_h, dev)
+    masks, cnt = [], None
+    if crops:     # resample, forward, resize back, count and paste: one pipeline call for the rank's crops
+        masks, cnt = segment_crops(engine, crops, mean, std, net_h, net_w, batch, paste=comp.paste_target(),
+                                   origins=[(b[0], b[1]) for b in boxes[lo:hi]])
     counts = torch.zeros(5, dtype=torch.int64, device=dev)
-    for b, m in zip(boxes[lo:hi], masks):
-        comp.paste(m, b[0], b[1])
-        counts += torch.bincount(m.flatten().long(), minlength=5)[:5]
+    if cnt is not None:
+        counts += torch.from_numpy(cnt.sum(0)).to(dev)
     if dist is not None and world > 1:
         dist.all_reduce(counts)
         dist.all_reduce(comp.map, op=dist.ReduceOp.MAX)    # max-composite is associative: one collective

@@ -74,33 +74,37 @@ def metric_right(hist):
 def segment_images(engine, images, mean, std, width, height, batch, want_net_maps=False):
     """images: list of HxWx3 uint8 BGR crops of any size -> list of class maps at crop size
     (with want_net_maps: (crop-size maps, network-resolution maps) -- the reference scores the latter, :202).
-    Crops already at network size go down the fused uint8 path (normalisation in the first kernel);
-    others are normalised + resized on the GPU exactly in the reference's order (:107-116).
-    With an encoder-only engine (modelType 2) every crop takes the second route and the 1/8-scale
-    logits are upsampled x8 bilinearly as the reference's `up` module does (:259-261,125-126)."""
+    A list of network-sized tiles goes down the fused uint8 pipeline (gs_espnet_segment_host); any other list goes through
+    the batched crop pipeline (gs_espnet_segment_crops_host), which normalises and resizes on the GPU exactly in the
+    reference's order (:107-116) for a whole batch per launch.  With an encoder-only engine (modelType 2) every crop is
+    resampled on its own and the 1/8-scale logits are upsampled x8 bilinearly as the reference's `up` module does
+    (:259-261,125-126)."""
     import torch
     out = [None] * len(images)
     net = [None] * len(images)
     enc = engine.encoder_only
-    native = [] if enc else [i for i, im in enumerate(images) if im.shape[:2] == (height, width)]
-    other = [i for i in range(len(images)) if enc or images[i].shape[:2] != (height, width)]
-    for s in range(0, len(native), batch):
-        idx = native[s:s + batch]
-        tiles = torch.from_numpy(np.stack([images[i] for i in idx])).to(engine.device)
-        mask, _, _ = engine.segment(tiles, mean, std, want_hist=False)
-        mask = mask.cpu().numpy()
-        for j, i in enumerate(idx):
-            out[i] = mask[j]
-            net[i] = mask[j]
+    if not enc and images:
+        if all(im.shape[:2] == (height, width) for im in images):
+            # network-sized tiles: the fused uint8 path (normalisation through the stem's table), pinned pipeline
+            masks, _ = engine.segment_host(np.stack(images), mean, std, batch=batch, want_hist=False)
+            out = list(masks)
+            net = list(masks)
+        else:
+            # any sizes: ONE call of the batched crop pipeline (resample -> forward -> argmax -> resize back per batch)
+            r = engine.segment_crops(images, mean, std, height, width, batch, want_masks=True, want_net_maps=want_net_maps,
+                                     want_hist=False)
+            out = r["masks"]
+            if want_net_maps:
+                net = list(r["net_maps"])
+        return (out, net) if want_net_maps else out
     from .engine import crop_preprocess, mask_resize_nearest
-    for s in range(0, len(other), batch):
-        idx = other[s:s + batch]
+    for s in range(0, len(images), batch):
+        idx = list(range(s, min(s + batch, len(images))))
         x = torch.empty((len(idx), 3, height, width), dtype=torch.float32, device=engine.device)
         for j, i in enumerate(idx):      # crop stage on the GPU: normalise + bilinear resize fused (:107-116)
             crop_preprocess(torch.from_numpy(images[i]).to(engine.device), mean, std, height, width, out=x[j])
         logits = engine.forward_logits(x)
-        if enc:
-            logits = torch.nn.functional.interpolate(logits, scale_factor=8, mode="bilinear", align_corners=False)
+        logits = torch.nn.functional.interpolate(logits, scale_factor=8, mode="bilinear", align_corners=False)
         cls = logits.max(1)[1].byte()       # :128
         cls_host = cls.cpu().numpy() if want_net_maps else None
         for j, i in enumerate(idx):

@@ -12,9 +12,10 @@
  * never throws; gs_last_error() gives the message of the calling thread's last failure.
  * Device pointers must belong to the HIP device that is current at the call.  A handle is bound
  * to that device and is not thread-safe; work is stream-ordered on the hipStream_t passed in
- * (NULL = the legacy default stream).  A handle has ONE activation workspace: work submitted for it on
- * different streams must be ordered by the caller (gs_espnet_segment_host uses streams of its own and
- * expects every earlier call on the handle to have completed).
+ * (NULL = the legacy default stream).  A handle has one activation workspace per LANE (one lane unless
+ * gs_espnet_set_lanes asked for more): work submitted for the same lane on different streams must be ordered by the
+ * caller.  The host pipelines (gs_espnet_segment_host, gs_espnet_segment_crops_host, gs_detector_detect_host) run on
+ * streams of their own, use lanes 0 and 1, and expect every earlier call on the handle to have completed.
  */
 #ifndef GLOMSEG_H
 #define GLOMSEG_H
@@ -38,6 +39,10 @@ typedef enum gs_status {
 const char *gs_last_error(void);
 /* ABI version, bumped on any signature change. */
 int gs_abi_version(void);
+/* How the library was compiled: GS_BUILD_DIAG = a -DGS_DIAG experiment build (timing variants that return wrong results by
+ * construction can be switched on through the environment); the product library returns 0 and reads no environment. */
+#define GS_BUILD_DIAG 1
+int gs_build_flags(void);
 
 /* ------------------------------------------------------------------ weights
  * One entry per state_dict tensor, named exactly as in models/espnet_fold*.pth
@@ -113,6 +118,58 @@ gs_status gs_crop_preprocess(const uint8_t *crop_bgr, int h, int w, const float 
                              int out_h, int out_w, float *out_chw, void *hip_stream);
 gs_status gs_mask_resize_nearest(const uint8_t *mask, int h, int w, int out_h, int out_w, uint8_t *out,
                                  void *hip_stream);
+
+/* ------------------------------------------------------------------ batched variable-size crops
+ * The loop body of VisualizeResults_iou.py:100-156 for the crops a slide really produces (make_seg_data.py:357-361: every
+ * merged box at its own size): normalise at crop resolution -> cv2.resize INTER_LINEAR to the network size -> /255 ->
+ * forward -> argmax -> cv2.resize INTER_NEAREST back to the crop size -> per-class counts of THAT map (:151-155), for a
+ * whole batch per launch: ONE descriptor-table kernel resamples every crop of the batch into the network's input, the mask
+ * comes straight from the decoder tail (no logits), ONE kernel resizes all masks back and counts, ONE kernel pastes them
+ * into the 1/ds slide map (eval_wsi_segmentation.py:311-312, np.max: overlapping crops of one launch meet through a
+ * compare-and-swap).  The arithmetic per pixel is that of gs_crop_preprocess / gs_mask_resize_nearest / gs_wsi_paste_max. */
+typedef struct gs_crop_desc {
+    int64_t in_off;  /* byte offset of the crop's uint8 BGR [h,w,3] pixels in the packed input buffer */
+    int64_t out_off; /* byte offset of its uint8 class map [h,w] in the packed output buffer (multiple of 4) */
+    int32_t h, w;
+    int32_t x1, y1;  /* level-0 origin of the crop on the slide (used by the paste only) */
+} gs_crop_desc;
+
+typedef struct gs_paste_target {
+    uint8_t *slide_map;   /* device uint8 [map_h,map_w], accumulated into */
+    int32_t map_h, map_w, ds;
+    const int *sx_lut;    /* device tables of gs_wsi_paste_max_lut, or both NULL for the regular grid */
+    const int *sy_lut;
+} gs_paste_target;
+
+#define GS_MAX_CROPS_PER_CALL 64
+
+/* Device-resident form, stream-ordered on lane `lane`: n <= GS_MAX_CROPS_PER_CALL crops packed in `packed_in` (device), their
+ * descriptors in HOST memory (they travel as kernel arguments).  Any of net_masks (device uint8 [n,net_h,net_w], the map the
+ * reference scores at network resolution, :202), packed_out (device, crop-size maps at out_off), hist (device uint64 [n,5],
+ * counts of the crop-size maps) and paste may be NULL, but not all of them. */
+gs_status gs_espnet_segment_crops(gs_espnet *h, int lane, const uint8_t *packed_in, const gs_crop_desc *descs, int n,
+                                  const float mean[3], const float std[3], int net_h, int net_w, uint8_t *net_masks,
+                                  uint8_t *packed_out, unsigned long long *hist, const gs_paste_target *paste, void *hip_stream);
+
+/* The same for an ensemble (cfg 5 definition: mean over members of softmax, each member with its own mean/std): every member
+ * resamples the crops with its own normalisation (the reference normalises BEFORE it resizes) and adds its probabilities in
+ * the decoder tail; the last member's tail writes the masks. */
+gs_status gs_espnet_ensemble_segment_crops(gs_espnet *const *models, int n_models, const uint8_t *packed_in, const gs_crop_desc *descs,
+                                           int n, const float *means, const float *stds, int net_h, int net_w, uint8_t *net_masks,
+                                           uint8_t *packed_out, unsigned long long *hist, const gs_paste_target *paste,
+                                           void *hip_stream);
+
+/* Host-to-host pipeline over a list of crops of any sizes (the whole loop :100-156): crops[i] is uint8 BGR [heights[i],
+ * widths[i],3] in host memory (page-locked buffers are DMA'd in place, pageable ones staged through pinned slots by a few
+ * threads); up to `batch` (<= GS_MAX_CROPS_PER_CALL) crops per step; uploads on a stream of their own, batches alternate
+ * between two compute streams (and two lanes when the handle has them), results come back by SDMA.  Outputs, each optional:
+ * masks[i] (host uint8 [heights[i],widths[i]]), net_masks (host uint8 [n_crops,net_h,net_w]), hist (host uint64 [n_crops,5],
+ * counts of the crop-size maps), paste + x1/y1 (level-0 origins).  n_models == 1 is the plain model; > 1 the ensemble.
+ * Returns when everything has arrived. */
+gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, const uint8_t *const *crops, const int *heights,
+                                       const int *widths, int n_crops, const float *means, const float *stds, int net_h,
+                                       int net_w, int batch, uint8_t *const *masks, uint8_t *net_masks,
+                                       unsigned long long *hist, const gs_paste_target *paste, const int *x1, const int *y1);
 
 /* WSI compositor (the consumer of the gathered masks; eval_wsi_segmentation.py:243-316,215-241,359-394).
  * The slide-level class map lives at 1/ds of level 0 (ds = 8 in the reference): pixel (X,Y) holds the
@@ -223,6 +280,13 @@ gs_status gs_detector_set_thresholds(gs_detector *h, float rpn_nms_iou, float de
 gs_status gs_detector_forward(gs_detector *h, const uint8_t *images_rgb, int n, int height, int width, float *boxes, float *scores,
                               float *classes, float *num, float *dbg_features, float *dbg_rpn, float *dbg_proposals,
                               float *dbg_head, void *hip_stream);
+
+/* Host-to-host scan of one slide's windows (the loop of detect_glomus_test.py:270-284 around sess.run): n equal-size uint8
+ * RGB windows in host memory (pageable ones staged through pinned slots by a few threads, page-locked ones DMA'd in place),
+ * `batch` windows per forward, uploads on a stream of their own one batch ahead of the forward.  Outputs in host memory:
+ * boxes [n,D,4], scores [n,D], classes [n,D], num [n] as gs_detector_forward writes them. */
+gs_status gs_detector_detect_host(gs_detector *h, const uint8_t *const *windows, int n, int height, int width, int batch,
+                                  float *boxes, float *scores, float *classes, float *num);
 
 #ifdef __cplusplus
 }

@@ -537,6 +537,224 @@ def test_crop_stage_kernels(torch_mod):
         assert np.array_equal(back, io.resize_nearest(m, w, h)), (h, w)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# batched variable-size crop entry (gs_espnet_segment_crops*): the path real detector crops take
+CROP_SIZES = [(37, 91), (300, 420), (64, 128), (200, 77), (130, 257), (96, 96), (411, 333)]
+
+
+def _crops(sizes, seed0=100):
+    from glomeruli_segmentation_amd.synth import synth_tile
+    return [synth_tile(seed0 + k, h, w, blobs=3) for k, (h, w) in enumerate(sizes)]
+
+
+def test_batched_crop_entry_against_oracle_and_per_crop_path(torch_mod, engine1, sd1):
+    """gs_espnet_segment_crops_host on crops of seven sizes (one of them network-sized, batches of 3 so that the last is
+    ragged) against (a) the oracle chain normalise_then_resize -> espnet_forward -> argmax -> resize_nearest
+    (VisualizeResults_iou.py:107-129) and (b) the per-crop path (gs_crop_preprocess -> forward -> torch.max ->
+    gs_mask_resize_nearest) bit for bit; counts are those of the crop-size maps (:151-155)"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.engine import crop_preprocess, mask_resize_nearest
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD
+    from oracle import espnet_oracle as orc
+    from oracle import image_oracle as io
+    mean, std = FOLD_MEAN_STD[1]
+    NH, NW = 64, 128
+    crops = _crops(CROP_SIZES)
+    r = engine1.segment_crops(crops, mean, std, NH, NW, batch=3, want_net_maps=True)
+    assert len(r["masks"]) == len(crops) and r["net_maps"].shape == (len(crops), NH, NW)
+    agree = total = 0
+    for i, c in enumerate(crops):
+        h, w = c.shape[:2]
+        assert r["masks"][i].shape == (h, w)
+        # (b) the per-crop path, bit for bit
+        x = crop_preprocess(torch.from_numpy(c).cuda(), mean, std, NH, NW)
+        cls = engine1.forward_logits(x[None]).max(1)[1].byte()[0]
+        assert np.array_equal(cls.cpu().numpy(), r["net_maps"][i]), i
+        assert np.array_equal(mask_resize_nearest(cls, h, w).cpu().numpy(), r["masks"][i]), i
+        # (a) the oracle chain
+        xo = io.normalise_then_resize(c, mean, std, NW, NH)
+        assert np.abs(x.cpu().numpy() - xo).max() <= 2e-6
+        ref_net = orc.argmax(orc.espnet_forward(xo, sd1))
+        agree += int((ref_net == r["net_maps"][i]).sum())
+        total += ref_net.size
+        assert np.array_equal(io.resize_nearest(r["net_maps"][i], w, h), r["masks"][i]), i      # :129 exactly
+        assert np.array_equal(np.bincount(r["masks"][i].ravel(), minlength=5)[:5], r["counts"][i]), i
+    assert agree / total >= 0.9995, agree / total
+    # pinned inputs are DMA'd in place: same result
+    pinned = [torch.from_numpy(c).pin_memory() for c in crops]
+    r2 = engine1.segment_crops(pinned, mean, std, NH, NW, batch=64)
+    assert all(np.array_equal(a, b) for a, b in zip(r["masks"], r2["masks"])) and np.array_equal(r["counts"], r2["counts"])
+
+
+def test_batched_crop_entry_full_size_and_paste(torch_mod, sd1):
+    """the crop sizes of the example slide at the real network size, two lanes: the pipeline's masks equal the per-crop
+    path, and its batched compare-and-swap paste (overlapping crops in one launch) equals pasting crop by crop -- on the
+    regular grid and under the reference's window walk"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.composite import SlideCompositor
+    from glomeruli_segmentation_amd.engine import EspnetEngine, crop_preprocess, mask_resize_nearest
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD
+    mean, std = FOLD_MEAN_STD[1]
+    ex = load_golden("merge.npz")["example_boxes"]
+    sizes = [(int(b[3] - b[1]), int(b[2] - b[0])) for b in ex[:10]]
+    crops = _crops(sizes, 300)
+    rng = np.random.default_rng(5)
+    SW, SH = 5003, 3100
+    # origins chosen so that crops overlap each other and some hang over the slide's edge region of partial windows
+    origins = [(int(rng.integers(0, SW - w)), int(rng.integers(0, SH - h))) for (h, w) in sizes]
+    eng = EspnetEngine(sd1, lanes=2)
+    for ref_windows in (False, True):
+        comp = SlideCompositor(SW, SH, "cuda", reference_windows=ref_windows)
+        r = eng.segment_crops(crops, mean, std, 512, 1024, batch=4, paste=comp.paste_target(), origins=origins)
+        one = SlideCompositor(SW, SH, "cuda", reference_windows=ref_windows)
+        for i, c in enumerate(crops):
+            if not ref_windows and i < 3:
+                x = crop_preprocess(torch.from_numpy(c).cuda(), mean, std, 512, 1024)
+                cls = eng.forward_logits(x[None]).max(1)[1].byte()[0]
+                assert np.array_equal(mask_resize_nearest(cls, *c.shape[:2]).cpu().numpy(), r["masks"][i]), i
+            one.paste(r["masks"][i], origins[i][0], origins[i][1])
+        assert torch.equal(one.map, comp.map)
+        assert int((comp.map > 0).sum()) > 0
+    eng.close()
+
+
+def test_batched_crop_entry_device_resident(torch_mod, engine1):
+    """gs_espnet_segment_crops (device-resident, descriptors as kernel arguments) = the host pipeline"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd import _lib
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD
+    mean, std = FOLD_MEAN_STD[1]
+    crops = _crops(CROP_SIZES[:5], 500)
+    ref = engine1.segment_crops(crops, mean, std, 64, 128, batch=8, want_net_maps=True)
+    descs, ioff, ooff = [], 0, 0
+    for c in crops:
+        d = _lib.CropDesc()
+        d.in_off, d.out_off, d.h, d.w = ioff, ooff, c.shape[0], c.shape[1]
+        descs.append(d)
+        ioff += c.size
+        ooff += (c.shape[0] * c.shape[1] + 3) // 4 * 4
+    packed = torch.from_numpy(np.concatenate([c.ravel() for c in crops])).cuda()
+    out = torch.zeros(ooff, dtype=torch.uint8, device="cuda")
+    net, hist = engine1.segment_crops_resident(packed, descs, mean, std, 64, 128, packed_out=out)
+    torch.cuda.synchronize()
+    assert np.array_equal(net.cpu().numpy(), ref["net_maps"]) and np.array_equal(hist.cpu().numpy(), ref["counts"])
+    o = out.cpu().numpy()
+    for d, m in zip(descs, ref["masks"]):
+        assert np.array_equal(o[d.out_off:d.out_off + d.h * d.w].reshape(d.h, d.w), m)
+    # error paths: too many crops, null outputs
+    with pytest.raises(_lib.GlomsegError):
+        engine1.segment_crops_resident(packed, descs * 20, mean, std, 64, 128)
+    with pytest.raises(_lib.GlomsegError):
+        engine1.segment_crops_resident(packed, descs, mean, std, 64, 128, want_net_maps=False, want_hist=False)
+
+
+def test_ensemble_on_crops(torch_mod):
+    """cfg 5 on real crops: every member resamples the crops with its own mean/std and adds its probabilities in the decoder
+    tail.  Network-sized crops give exactly gs_espnet_ensemble_forward's masks; other sizes are checked against the definition
+    evaluated with torch on the members' logits"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.engine import EspnetEngine, crop_preprocess, ensemble_segment, segment_crops_host
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD
+    folds = [1, 2, 3]
+    engines = [EspnetEngine(load_weights(f)) for f in folds]
+    ms = [FOLD_MEAN_STD[f] for f in folds]
+    NH, NW = 64, 128
+    crops = _crops([(64, 128), (64, 128), (150, 99), (301, 420), (64, 128)], 700)
+    r = segment_crops_host(engines, ms, crops, NH, NW, batch=2, want_net_maps=True)
+    same = [i for i, c in enumerate(crops) if c.shape[:2] == (NH, NW)]
+    mask, hist = ensemble_segment(engines, torch.from_numpy(np.stack([crops[i] for i in same])).cuda(), ms)
+    for j, i in enumerate(same):
+        assert np.array_equal(mask[j].cpu().numpy(), r["net_maps"][i]), i
+        assert np.array_equal(hist[j].cpu().numpy(), r["counts"][i]), i
+    agree = total = 0
+    for i, c in enumerate(crops):
+        prob = 0
+        for e, (m, s) in zip(engines, ms):
+            x = crop_preprocess(torch.from_numpy(c).cuda(), m, s, NH, NW)
+            prob = prob + torch.softmax(e.forward_logits(x[None]), 1) / len(engines)
+        ref = prob.max(1)[1][0].byte().cpu().numpy()
+        agree += int((ref == r["net_maps"][i]).sum())
+        total += ref.size
+    assert agree / total >= 0.9995, agree / total
+    for e in engines:
+        e.close()
+
+
+def test_ensemble_large_batch_equals_small_batches(torch_mod):
+    """128 tiles of 56 x 1024 in one ensemble pass: the decoder tail then works in bands of 8 rows over 28, so the last band is
+    shifted up and shares rows with its neighbour -- rows whose probabilities must be accumulated exactly once.  The same
+    tiles two at a time (bands of 2 rows, no shared rows) give the reference masks"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.engine import EspnetEngine, ensemble_segment
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    folds = [1, 2, 3]
+    engines = [EspnetEngine(load_weights(f)) for f in folds]
+    ms = [FOLD_MEAN_STD[f] for f in folds]
+    base = np.stack([synth_tile(60 + k, 56, 1024, blobs=5) for k in range(8)])
+    tiles = torch.from_numpy(np.concatenate([base] * 16)).cuda()
+    big, bh = ensemble_segment(engines, tiles, ms)
+    for s in range(0, 8, 2):
+        small, sh = ensemble_segment(engines, tiles[s:s + 2], ms)
+        for rep in (0, 5, 15):
+            assert torch.equal(big[rep * 8 + s:rep * 8 + s + 2], small), (s, rep)
+            assert torch.equal(bh[rep * 8 + s:rep * 8 + s + 2], sh), (s, rep)
+    for e in engines:
+        e.close()
+
+
+def test_calls_need_no_manual_synchronisation(torch_mod, sd1):
+    """segment() on the current stream or on a lane, then a host pipeline call, with no synchronisation by the caller
+    (the wrapper orders them: engine.quiesce)"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.engine import EspnetEngine
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    mean, std = FOLD_MEAN_STD[1]
+    tiles = np.stack([synth_tile(900 + k, 128, 256, blobs=3) for k in range(8)])
+    dev = torch.from_numpy(tiles).cuda()
+    eng = EspnetEngine(sd1, lanes=2)
+    ref, _, _ = eng.segment(dev, mean, std)
+    ref = ref.cpu().numpy()
+    other = np.stack([synth_tile(950 + k, 128, 256, blobs=3) for k in range(8)])
+    ref_other, _ = eng.segment_host(other, mean, std, batch=4)
+    for _ in range(3):
+        a, _, _ = eng.segment(dev, mean, std, lane=0)
+        b, _, _ = eng.segment(dev, mean, std, lane=1)
+        h, _ = eng.segment_host(other, mean, std, batch=4)          # workspaces 0 and 1, the library's own streams
+        c, _, _ = eng.segment(dev, mean, std)                       # workspace 0 again, on the current stream
+        assert np.array_equal(h, ref_other)
+        eng.wait_lanes()
+        assert np.array_equal(a.cpu().numpy(), ref) and np.array_equal(b.cpu().numpy(), ref) and np.array_equal(c.cpu().numpy(), ref)
+    eng.close()
+
+
+def test_tall_tiles_count_without_overflow(torch_mod, sd1):
+    """the decoder tail packs a lane's per-class counts into 12-bit fields: a tall constant tile (one class everywhere, bands
+    of hundreds of rows) must still count every pixel"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.engine import EspnetEngine
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD
+    mean, std = FOLD_MEAN_STD[1]
+    eng = EspnetEngine(sd1)
+    tile = np.empty((2, 2304, 136, 3), dtype=np.uint8)
+    tile[:] = np.array([204, 170, 199], dtype=np.uint8)
+    mask, hist, _ = eng.segment(torch.from_numpy(tile).cuda(), mean, std)
+    m = mask.cpu().numpy()
+    for k in range(2):
+        assert np.array_equal(np.bincount(m[k].ravel(), minlength=5)[:5], hist[k].cpu().numpy())
+    eng.close()
+
+
+def test_host_pipeline_pageable_large_batches(torch_mod, engine1):
+    """pageable numpy tiles in batches large enough (>= 8 MB) for the threaded staging copies, against the resident path"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    mean, std = FOLD_MEAN_STD[1]
+    tiles = np.stack([synth_tile(40 + k, 512, 1024, blobs=4) for k in range(13)])       # 1.5 MB each, 9.4 MB per batch of 6
+    masks, hist = engine1.segment_host(tiles, mean, std, batch=6)
+    ref, rh, _ = engine1.segment(torch.from_numpy(tiles).cuda(), mean, std)
+    assert np.array_equal(masks, ref.cpu().numpy()) and np.array_equal(hist, rh.cpu().numpy())
+
+
 def _random_crops(rng, W, H, n):
     boxes, crops = [], []
     for _ in range(n):
@@ -760,13 +978,13 @@ def test_slide_pipeline_detect_merge_crop_segment_composite(torch_mod, engine1):
     # stage-by-stage: segment one crop alone and paste it alone
     b = res["boxes"][0]
     crop = np.ascontiguousarray(read_region(b[0], b[1], b[2] - b[0], b[3] - b[1], 1.0)[:, :, ::-1])
-    alone = pipeline.segment_crops(engine1, [crop], mean, std, 512, 1024)[0]
-    assert torch.equal(alone, res["masks"][0])
-    total = sum(int(m.numel()) for m in res["masks"])
+    alone = pipeline.segment_crops(engine1, [crop], mean, std, 512, 1024)[0][0]
+    assert np.array_equal(alone, res["masks"][0])
+    total = sum(int(m.size) for m in res["masks"])
     assert int(res["counts"].sum()) == total
     m = res["map"].cpu().numpy()
     X0, Y0 = -(-b[0] // 8), -(-b[1] // 8)
-    sub = alone.cpu().numpy()[(Y0 * 8 - b[1])::8, (X0 * 8 - b[0])::8]
+    sub = alone[(Y0 * 8 - b[1])::8, (X0 * 8 - b[0])::8]
     assert np.array_equal(m[Y0:Y0 + sub.shape[0], X0:X0 + sub.shape[1]], sub)
 
 
@@ -892,7 +1110,7 @@ def test_slide_pipeline_with_the_gpu_detector(torch_mod, engine1):
     assert calls["windows"] == len(plan.origins()) and calls["n"] == -(-len(plan.origins()) // 8)
     assert len(res["boxes"]) >= 1
     assert len(res["masks"]) == len(res["boxes"])
-    total = sum(int(m.numel()) for m in res["masks"])
+    total = sum(int(m.size) for m in res["masks"])
     assert int(res["counts"].sum()) == total
     # the detect leg alone, window by window, gives the rows the batched leg gave
     rows_b = detect.scan_slide(lambda x, y, w, h: read_region(x, y, w, h, 8.0), detector, plan, 0.3, "s", "p", "f", batch=8,

@@ -286,6 +286,11 @@ def test_detector_box_postprocessing_and_csv():
     scores = np.array([[0.9, 0.61, 0.2]], dtype=np.float32)
     bs = detect.boxes_from_detector(boxes, scores, 1098, 1000, thresh=0.6)
     assert [b[:4] for b in bs] == [[int(1098 * np.float32(0.2)), 100, int(1098 * np.float32(0.6)), 500], [0, 0, 1098, 1000]]
+    # known answer for the promotion rule: the reference's NumPy 1.x forms WINDOW_X * xmin (Python int x float32 scalar) in
+    # float64 -- 1098 * float64(float32(4/1098)) = 3.99999998... -> 3 -- where NumPy 2 would stay in float32 and give 4
+    edge = np.array([[[np.float32(2 / 1000.0), np.float32(4 / 1098.0), 0.5, 0.5]]], dtype=np.float32)
+    assert detect.boxes_from_detector(edge, np.array([[0.7]], dtype=np.float32), 1098, 1000, 0.6)[0][:4] == \
+        [int(1098 * float(np.float32(4 / 1098.0))), int(1000 * float(np.float32(2 / 1000.0))), 549, 500] == [3, 2, 549, 500]
     now = datetime.datetime(2020, 1, 2, 3, 4, 5)
     rows = detect.csv_rows(bs, 7905, 0, 8.0, "site", "PAS-001", "PAS-001.ndpi", now)
     x1 = 7905 + bs[0][0] * 8.0
