@@ -16,6 +16,11 @@ Crop JSON decoding (the reference stores the original RGB crop in imageData, SUR
 class maps directly.
 """
 import ctypes
+import glob
+import json
+import os
+import sys
+from argparse import ArgumentParser
 
 import numpy as np
 import torch
@@ -112,3 +117,135 @@ class SlideCompositor:
             _lib.check(self.lib.gs_confusion_u8(self.map.data_ptr(), gt.data_ptr(), self.map.numel(), classes, hist.data_ptr(),
                                                 _sp(self.device)))
         return hist
+
+
+# --------------------------------------------------------------------------- command line (prediction WSI)
+def relabel(img):
+    """eval_wsi_segmentation.py:49-55: Cityscapes ids back to 0..4 (identity on a map that is already 0..4)."""
+    lut = np.arange(256, dtype=np.uint8)
+    for src, dst in ((13, 4), (12, 3), (11, 2), (8, 1), (7, 0)):
+        lut[src] = dst
+    return lut[img]
+
+
+def load_class_map(json_path):
+    """The class map a segmentation JSON stands for: the PNG named by classMapPath (what segment.py always writes beside
+    the JSON), else the decoded imageData -- the reference decodes imageData (:287-297), which only holds a class map
+    when the segmentation was written with the variant commented out at VisualizeResults_iou.py:178 (--imageData classmap)."""
+    import base64
+    import io
+    from PIL import Image
+    with open(json_path) as f:
+        data = json.load(f)
+    if data.get("classMapPath"):
+        return np.asarray(Image.open(os.path.join(os.path.dirname(json_path), data["classMapPath"])))
+    if data.get("imageData"):
+        img = np.asarray(Image.open(io.BytesIO(base64.b64decode(data["imageData"]))))
+        if img.ndim == 2:
+            return img
+    raise ValueError("%s holds no class map (imageData is the original crop): re-run the segmentation with --imageData classmap, "
+                     "or keep the *_classmap.png files beside the JSON" % json_path)
+
+
+def build_parser():
+    """the prediction branch of eval_wsi_segmentation.py:397-422 (flags kept; the ground-truth evaluation flags are accepted
+    and must stay unset: GT tooling -- annotation XML, labelme shapes -- is outside the rebuilt path)."""
+    p = ArgumentParser(description='merge cropped glomerular segmented images')
+    p.add_argument('--staining', dest='staining', type=str, required=True)
+    p.add_argument('--merged_detection_result_csv', dest='input_csv', type=str, required=True)
+    p.add_argument('--target_list', dest='target_list', type=str, required=True)
+    p.add_argument('--wsi_dir', dest='wsi_dir', type=str, required=True)
+    p.add_argument('--segmentation_pred_json_dir', dest='seg_pred_json_dir', type=str, required=True)
+    p.add_argument('--object_detection_gt_xml_dir', dest='ob_gt_xml_dir', type=str, default=None)
+    p.add_argument('--segmentation_gt_json_dir', dest='seg_gt_json_dir', type=str, default=None)
+    p.add_argument('--segmentation_gt_png_dir', dest='gt_png_dir', type=str, default=None)
+    p.add_argument('--output_dir', dest='output_dir', type=str, default='./output/seg_data_pred')
+    p.add_argument('--window_size', dest='window_size', type=int, default=2400)
+    p.add_argument('--classes', dest='classes', type=int, default=5)
+    p.add_argument('--no_save', dest='no_save', action='store_true')
+    p.add_argument('--gpu_id', dest='gpu_id', type=int, default=0)
+    return p
+
+
+def slide_size(wsi_dir, file_key, target_meta):
+    """slide.dimensions (:340-357) through OpenSlide when it is installed; else the size the target list records for the
+    specimen (the PNG-branch metadata), else the size of a PNG slide found under wsi_dir/file_key times its downsample."""
+    ndpi = glob.glob(os.path.join(wsi_dir, file_key, "*ndpi"))
+    if ndpi:
+        try:
+            import openslide
+            with openslide.open_slide(ndpi[0]) as s:
+                return s.dimensions
+        except ImportError:
+            pass
+    m = target_meta.get(file_key)
+    if m and m["width"] > 0:
+        return m["width"], m["height"]
+    raise RuntimeError("size of slide %s unknown: OpenSlide is not installed and the target list has no metadata line for it" % file_key)
+
+
+def generate_pred_wsi(args, out=sys.stdout):
+    """generate_pred_wsi (:359-394): for every slide of the merged list, the crops' class maps max-composited under the
+    reference's 2400-px window walk into the 1/8 map, coloured and blended over the 1/8 slide image -> <slide>_pred.jpg
+    (+ <slide>_pred_classmap.png, additive)."""
+    import torch
+    from PIL import Image
+    from . import detect, merge
+    if args.window_size != WINDOW:
+        raise ValueError("the window walk is built for the reference's window size %d" % WINDOW)
+    boxes_of, order = merge.read_merged_csv(args.input_csv)
+    target_meta = {}
+    if os.path.isfile(args.target_list):
+        for line in open(args.target_list):
+            m = detect.parse_target_line(line)
+            if m:
+                target_meta[m["specimen_id"].replace(' ', '')] = m
+    os.makedirs(args.output_dir, exist_ok=True)
+    dev = torch.device("cuda", args.gpu_id)
+    results = {}
+    for key in order:
+        jsons = glob.glob(os.path.join(args.seg_pred_json_dir, key, "*.json"))
+        w, h = slide_size(args.wsi_dir, key, target_meta)
+        comp = SlideCompositor(w, h, dev, reference_windows=True)
+        used = 0
+        for b in boxes_of[key]:
+            name = merge.crop_name(b)                                         # :268
+            hits = [j for j in jsons if name in os.path.basename(j)]
+            assert len(hits) <= 1
+            if not hits:
+                continue                                                      # :272-274: a crop without a segmentation
+            cm = relabel(np.ascontiguousarray(load_class_map(hits[0]), dtype=np.uint8))
+            if cm.shape != (b[3] - b[1], b[2] - b[0]):
+                raise ValueError("%s: class map %s does not fit its box %s" % (hits[0], cm.shape, b[:4]))
+            assert int(cm.max()) < args.classes                               # :314
+            comp.paste(cm, b[0], b[1])
+            used += 1
+        mh, mw = comp.map.shape
+        small = np.zeros((mh, mw, 3), dtype=np.uint8)
+        pngs = glob.glob(os.path.join(args.wsi_dir, key, "*.PNG")) + glob.glob(os.path.join(args.wsi_dir, key, "*.png"))
+        if pngs:          # the 1/8 slide image of the PNG branch, cropped / padded to the map
+            with Image.open(pngs[0]) as im:
+                rgb = np.asarray(im.convert("RGB"))
+            hh, ww = min(mh, rgb.shape[0]), min(mw, rgb.shape[1])
+            small[:hh, :ww] = rgb[:hh, :ww, ::-1]
+        blended = comp.overlay(small).cpu().numpy()
+        results[key] = {"map": comp.map.cpu().numpy(), "crops": used}
+        if not args.no_save:
+            Image.fromarray(np.ascontiguousarray(blended[:, :, ::-1])).save(os.path.join(args.output_dir, key + "_pred.jpg"))
+            Image.fromarray(results[key]["map"]).save(os.path.join(args.output_dir, key + "_pred_classmap.png"))
+        print("{}: {} crops composited on a {} x {} map".format(key, used, mw, mh), file=out)
+    return results
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.seg_gt_json_dir or args.gt_png_dir or args.ob_gt_xml_dir:
+        print("the ground-truth evaluation branch (annotation XML / labelme shapes) is outside the rebuilt path; "
+              "leave the *_gt_* arguments unset to compose the prediction WSI", file=sys.stderr)
+        return 2
+    generate_pred_wsi(args)
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -24,7 +24,8 @@ def free_port():
 
 
 def spawn_ranks(script, argv, n, poll_s=0.05, grace_s=5.0, out=None, err=None):
-    """Start `python script argv...` n times with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's stdout, and
+    """Start `python script argv...` (or, when `script` is a list, that command prefix -- e.g. [sys.executable, "-m",
+    "glomeruli_segmentation_amd.segment"]) n times with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's stdout, and
     watch ALL children: as soon as one exits non-zero the others are terminated (they would sit in a rendezvous or a
     collective until its timeout, holding their GPUs) and the failing rank's stderr tail is reported.  Returns the exit code
     for the parent (0 only if every rank returned 0).  Fresh child processes only; nothing is restarted."""
@@ -41,7 +42,8 @@ def spawn_ranks(script, argv, n, poll_s=0.05, grace_s=5.0, out=None, err=None):
     for r in range(n):
         log = tempfile.TemporaryFile()
         logs.append(log)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+        cmd = list(script) if isinstance(script, (list, tuple)) else [sys.executable, os.path.abspath(script)]
+        procs.append(subprocess.Popen(cmd + list(argv), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                                       stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=log))
 
     def tail(f, limit=3000):

@@ -10,6 +10,10 @@ Pinned by golden vectors produced by running the reference's own class (tests/go
 A rectangle is a list [x1, y1, x2, y2, confidence, area, overlap_with_candidate].
 """
 import csv
+import os
+import sys
+import time
+from argparse import ArgumentParser
 
 UNCONDITIONAL_MERGE_THRESHOLD = 0.6      # merge_overlaped_glomus.py:31
 SIDE_LENGTH_MERGE_THRESHOLD = 30         # micrometres, :33
@@ -156,3 +160,95 @@ def merge_csv(detected_csv, merged_csv, mpp_of, overlap_threshold, conf_threshol
             mpp_x, mpp_y = mpp_of(specimen, file_name)
             rects = merge_detections(dets, mpp_x, mpp_y, overlap_threshold, conf_threshold)
             out.writelines(merged_csv_rows(site, specimen, file_name, rects))
+
+
+# --------------------------------------------------------------------------- command line
+PNG_EXT = ('.png', '.PNG')
+
+
+def read_target_list(path):
+    """run() (:62-95): {file id (second path element of a line's first field): metadata}; short lines zero the metadata."""
+    out = {}
+    if path and os.path.isfile(path):
+        with open(path, 'r') as f:
+            for line in f.readlines():
+                parts = line.strip().split(',')
+                meta = dict(org_slide_width=0, org_slide_height=0, org_slide_objective_power=0.0, slide_downsample=0.0, mpp_x=0.0, mpp_y=0.0)
+                if len(parts) >= 7:
+                    meta = dict(org_slide_width=int(parts[1]), org_slide_height=int(parts[2]), org_slide_objective_power=float(parts[3]),
+                                slide_downsample=float(parts[4]), mpp_x=float(parts[5]), mpp_y=float(parts[6]))
+                ids = parts[0].split('/')
+                if len(ids) > 1:
+                    out[ids[1]] = meta
+    return out
+
+
+def mpp_lookup(target_list, annotation_dir, staining_dir):
+    """check_mpp (:342-362): PNG slides take mpp from the target list (keyed by the file name without extension); any other
+    slide is opened with OpenSlide.  OpenSlide is not part of this stack: without it a non-PNG slide falls back on the target
+    list when the list names it, and fails loudly otherwise."""
+    def mpp_of(specimen, file_name):
+        body, ext = os.path.splitext(file_name)
+        if ext not in PNG_EXT:
+            try:
+                import openslide
+            except ImportError:
+                openslide = None
+            if openslide is not None:
+                with openslide.open_slide(os.path.join(annotation_dir, staining_dir, specimen, file_name)) as slide:
+                    return (float(slide.properties[openslide.PROPERTY_NAME_MPP_X]), float(slide.properties[openslide.PROPERTY_NAME_MPP_Y]))
+            if body not in target_list or not target_list[body]['mpp_x'] > 0:
+                raise RuntimeError("%s: reading the resolution of a non-PNG slide needs the openslide package (not installed) or a "
+                                   "target-list line with its metadata" % file_name)
+        props = target_list[body]          # KeyError for an unknown file, as in the reference
+        return float(props['mpp_x']), float(props['mpp_y'])
+    return mpp_of
+
+
+def build_parser():
+    """argparse surface of merge_overlaped_glomus.py:364-383."""
+    p = ArgumentParser(description='MERGE_OVERLAPPED_GLOMUS')
+    p.add_argument('--staining', dest='staining', type=str, default='OPT_PAS')
+    p.add_argument('--target_list', dest='target_list', type=str)
+    p.add_argument('--detected_list', dest='input_file', type=str)
+    p.add_argument('--output_dir', dest='output_dir', type=str)
+    p.add_argument('--output_file_ext', dest='training_type', type=str, default='')
+    p.add_argument('--conf_threshold', dest='conf_threshold', type=float, default=0.6)
+    p.add_argument('--data_dir', dest='annotation_dir', type=str)
+    p.add_argument('--overlap_threshold', dest='overlap_threshold', type=float)
+    return p
+
+
+def run(args, out=sys.stdout):
+    """MargeOverlapedGlomus.run (:56-166): <staining>_GlomusMergedList_<ext>.csv and ..._log.csv in --output_dir."""
+    from .detect import staining_dir
+    target_list = read_target_list(args.target_list)
+    mpp_of = mpp_lookup(target_list, args.annotation_dir or '', staining_dir(args.staining))
+    body = args.staining + '_GlomusMergedList_' + args.training_type
+    merged_path = os.path.join(args.output_dir, body + '.csv')
+    log_path = os.path.join(args.output_dir, body + '_log.csv')
+    with open(merged_path, "w") as merged, open(log_path, "w") as log:
+        t0 = time.time()
+        for site, specimen, file_name, dets in read_detections_csv(args.input_file):
+            mpp_x, mpp_y = mpp_of(specimen, file_name)
+            rects = merge_detections(dets, mpp_x, mpp_y, args.overlap_threshold, args.conf_threshold)
+            merged.writelines(merged_csv_rows(site, specimen, file_name, rects))
+            merged.flush()
+            print('"{}":{}'.format(file_name, rects), file=out)
+            log.write('"{}",{}\n'.format(file_name, time.time() - t0))
+            log.flush()
+            t0 = time.time()
+    return merged_path
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if not args.input_file or not args.output_dir or args.overlap_threshold is None:
+        print("--detected_list, --output_dir and --overlap_threshold are required", file=sys.stderr)
+        return 2
+    run(args)
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

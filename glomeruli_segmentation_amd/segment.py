@@ -6,10 +6,13 @@ eager loop replaced by batched HIP passes.
     python -m glomeruli_segmentation_amd.segment --rgb_data_dir DIR --weights espnet_fold1.pth \
         --mean 204.60071 170.19359 199.57469 --std 20.61257 42.92207 28.401505 --gpu_id 0 ...
 
-Additive flags: --batch (tiles per GPU pass), torchrun-style multi-process sharding is picked up
-from RANK/WORLD_SIZE (each rank takes a contiguous range of the sorted crop list).
+Additive flags: --batch (tiles per GPU pass), --imageData.  Started one process per GPU (torchrun / RANK, LOCAL_RANK,
+WORLD_SIZE) every rank takes a contiguous range of the sorted crop list on its own GPU, and rank 0 writes the SAME summary
+files a single process writes: CSV rows gathered in order, the confusion matrix summed over ranks.
 """
+import base64
 import glob
+import io
 import json
 import os
 import sys
@@ -44,6 +47,10 @@ def build_parser():
     p.add_argument('--overlay', action='store_true')
     p.add_argument('--classes', default=5, type=int)
     p.add_argument('--batch', default=32, type=int, help='tiles per GPU pass (additive flag)')
+    p.add_argument('--imageData', default='orig', choices=['orig', 'classmap', 'none'],
+                   help="what the JSON's imageData holds (additive flag): 'orig' = the original crop as the reference stores it "
+                        "(VisualizeResults_iou.py:179), 'classmap' = the class map (the variant commented out at :178, which is "
+                        "what eval_wsi_segmentation.py decodes), 'none' = null (the class map is always written beside the JSON)")
     return p
 
 
@@ -115,13 +122,25 @@ def segment_images(engine, images, mean, std, width, height, batch, want_net_map
     return (out, net) if want_net_maps else out
 
 
-def evaluate(args, engine, rgb_list, label_list):
+def img_arr_to_b64(arr):
+    """labelme.utils.img_arr_to_b64 (labelme 3.16): the array as a PNG, base64.  The reference hands it the cv2 (BGR) crop,
+    which PIL takes for RGB: the stored picture has its channels swapped, and so has this one."""
+    from PIL import Image
+    f = io.BytesIO()
+    Image.fromarray(arr).save(f, format='PNG')
+    return base64.b64encode(f.getvalue()).decode('utf-8')
+
+
+def evaluate(args, engine, rgb_list, label_list, rank=0, world=1, dist=None):
+    """evaluateModel (:84-241) over this rank's range; the summary files are written by rank 0 for all ranks."""
+    from PIL import Image
+    from .contours import labelme_dict
+    from .shard import gather_rows, reduce_sum_to_all
     mean = [float(v) for v in args.mean]
     std = [float(v) for v in args.std]
     os.makedirs(args.savedir, exist_ok=True)
-    total_hist = None
-    dataset_d = defaultdict(lambda: defaultdict(int))
-    rows_pixel, rows_acc = [], []
+    total_hist = np.zeros((args.classes, args.classes), dtype=np.int64)
+    rows_pixel, rows_acc, seen = [], [], []
     for s in range(0, len(rgb_list), args.batch):
         names = rgb_list[s:s + args.batch]
         images = [imageops.imread_bgr(n) for n in names]
@@ -132,29 +151,31 @@ def evaluate(args, engine, rgb_list, label_list):
             stem = name.rsplit(".", 1)[0]
             odir = os.path.join(args.savedir, patient)
             os.makedirs(odir, exist_ok=True)
-            if args.colored:
-                colour = imageops.colourise(cmap)
+            overlayed = None
+            if args.colored or label_name is not None:
+                colour = imageops.colourise(cmap)                                                  # :139-143
+                overlayed = imageops.add_weighted(img, 0.4, colour, 0.6)
                 if args.overlay:
-                    imageops.imwrite_bgr(os.path.join(odir, stem + "_overlay.jpg"), imageops.add_weighted(img, 0.4, colour, 0.6))
+                    imageops.imwrite_bgr(os.path.join(odir, stem + "_overlay.jpg"), overlayed)    # :145-148
                     imageops.imwrite_bgr(os.path.join(odir, stem + "_org.png"), img)
             counts = [int(np.count_nonzero(cmap == c)) for c in range(5)]                         # :151-155
             rows_pixel.append("{},{},{},{},{},{},{}\n".format(patient, name.replace(args.img_extn, 'png'), *counts))
             out_map = imageops.relabel_city(cmap) if args.cityFormat else cmap                     # :158-159
-            # The reference stores the ORIGINAL crop in the JSON's imageData (:179) although the WSI
-            # compositor reads it as a class map; this build writes the class map
-            # itself beside the JSON and records its name; polygons come from contours.py (the build's
-            # restatement of boundary_extractor.py, cv2 being absent).
-            from PIL import Image
+            # The class map is always written beside the JSON (additive: the WSI compositor takes it from there); what the
+            # JSON's imageData holds follows --imageData (the reference: the ORIGINAL crop, :179, although
+            # eval_wsi_segmentation.py decodes it as a class map -- SURVEY quirks).
             Image.fromarray(out_map).save(os.path.join(odir, stem + "_classmap.png"))
-            from .contours import labelme_dict
+            body = labelme_dict(out_map, name, stem + "_classmap.png")                             # :161-177
+            body["imageData"] = (img_arr_to_b64(img) if args.imageData == 'orig' else
+                                 img_arr_to_b64(np.ascontiguousarray(out_map, dtype=np.uint8)) if args.imageData == 'classmap' else None)
             with open(os.path.join(odir, name.replace(args.img_extn, 'json')), 'w') as f:
-                json.dump(labelme_dict(out_map, name, stem + "_classmap.png"), f, indent=4)        # :161-182
+                json.dump(body, f, indent=4)
             if label_name is not None:
                 assert os.path.basename(img_name) == os.path.basename(label_name)
                 lab = np.asarray(Image.open(label_name))
                 assert lab.shape[:2] == img.shape[:2]
-                # the reference scores at network resolution (:195-203): the label is nearest-resized to the network
-                # size and compared with img_out.max(1)[1] itself, NOT with the map that went to crop size and back
+                # the reference scores at network resolution (:195-203): the label is nearest-resized to the network size and
+                # compared with img_out.max(1)[1] itself, NOT with the map that went to crop size and back
                 if lab.shape[:2] == (args.inHeight, args.inWidth):
                     lab_r = lab
                 else:
@@ -163,33 +184,50 @@ def evaluate(args, engine, rgb_list, label_list):
                     lab_r = mask_resize_nearest(torch.from_numpy(np.array(lab, dtype=np.uint8)).to(engine.device),
                                                 args.inHeight, args.inWidth).cpu().numpy()      # :195 cv2.resize INTER_NEAREST
                 hist = confusion(net_map.ravel(), lab_r.ravel(), args.classes)
-                total_hist = hist if total_hist is None else total_hist + hist
+                total_hist += hist
                 uniq = np.unique(lab_r)
-                for v in uniq.tolist():
-                    dataset_d[patient][v] += 1
+                seen.append((patient, uniq.tolist()))
                 _, _, per_iu, _ = metric_right(hist)
                 union = hist.sum(1) + hist.sum(0) - np.diag(hist)
                 miou_each = np.nanmean(np.diag(hist)[uniq] / union[uniq])                           # :208-209
                 flags = [1 if (uniq == c).any() else 0 for c in range(1, 5)]
                 rows_acc.append("{}/{},{},{},{},{},{},{},{},{},{},{}\n".format(
                     patient, name.replace(args.img_extn, 'png'), *flags, *per_iu[:5], miou_each))
-    rank = int(os.environ.get("RANK", "0"))
-    suffix = "" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else ".rank%d" % rank
-    with open(os.path.join(args.savedir, "summary_pixel.csv" + suffix), "w") as f:
+                # original | ground truth overlay | prediction overlay (:215-231)
+                gt_colour = imageops.colourise(np.minimum(lab, len(imageops.PALETTE) - 1).astype(np.uint8))
+                combined = np.concatenate([img, imageops.add_weighted(img, 0.4, gt_colour, 0.6), overlayed], axis=1)
+                cdir = os.path.join(args.savedir, "combined_images", patient)
+                os.makedirs(cdir, exist_ok=True)
+                imageops.imwrite_bgr(os.path.join(cdir, name.replace(args.img_extn, 'png')), combined)
+    # ---- one set of summary files (:91-98,232-241): rows in the order of the sorted list, one confusion matrix
+    rows_pixel = gather_rows(rows_pixel, rank, world, dist)
+    rows_acc = gather_rows(rows_acc, rank, world, dist)
+    seen = gather_rows(seen, rank, world, dist)
+    total_hist = reduce_sum_to_all(total_hist, dist, getattr(engine, "device", None))
+    have_labels = label_list and label_list[0] is not None
+    if world > 1:
+        have_labels = bool(reduce_sum_to_all(np.array([1 if have_labels else 0]), dist, getattr(engine, "device", None))[0])
+    if rank != 0:
+        return total_hist
+    with open(os.path.join(args.savedir, "summary_pixel.csv"), "w") as f:
         f.write("patient_id, filename, background, glomerulus, crescent, sclerosis, mesangium\n")
         f.writelines(rows_pixel)
-    with open(os.path.join(args.savedir, "summary_accuracy.csv" + suffix), "w") as f:
+    with open(os.path.join(args.savedir, "summary_accuracy.csv"), "w") as f:
         f.write("filename,glomerulus, crescent, sclerosis, mesangium, background iou,glomerulus iou,crescent iou,"
                 "sclerosis iou, mesangium iou,mIoU\n")
         f.writelines(rows_acc)
-    with open(os.path.join(args.savedir, "summary_dataset.csv" + suffix), "w") as f:
+    with open(os.path.join(args.savedir, "summary_dataset.csv"), "w") as f:
         f.write("patient_id, glomerulus, crescent, sclerosis, mesangium\n")
-        if total_hist is not None:
+        if have_labels:
+            dataset_d = defaultdict(lambda: defaultdict(int))
+            for patient, values in seen:
+                for v in values:
+                    dataset_d[patient][v] += 1
             for patient, vals in dataset_d.items():
                 f.write(patient + "".join(",{}".format(vals[i]) for i in range(1, args.classes)) + "\n")
-    if total_hist is not None:
+    if have_labels:
         o, pa, pi, m = metric_right(total_hist)
-        with open(os.path.join(args.savedir, "overall_accuracy.txt" + suffix), "w") as f:
+        with open(os.path.join(args.savedir, "overall_accuracy.txt"), "w") as f:
             f.write("overall_acc:{}, per_class_acc:{}, per_class_iou:{}, mIOU:{}".format(o, pa, pi, m))
     return total_hist
 
@@ -216,9 +254,13 @@ def main(argv=None):
         return 2
     import torch
     from .engine import EspnetEngine
-    torch.cuda.set_device(args.gpu_id)
-    print('cuda:{}'.format(args.gpu_id))
-    lo, hi = rank_range(len(rgb_list), int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+    from .shard import init_from_env
+    rank, world, local, dist = init_from_env()
+    # one process per GPU: every rank on its own device (LOCAL_RANK); a single process keeps the reference's --gpu_id
+    dev_id = args.gpu_id if world == 1 or os.environ.get("GLOMSEG_ONE_GPU") == "1" else local
+    torch.cuda.set_device(dev_id)
+    print('cuda:{}'.format(dev_id))
+    lo, hi = rank_range(len(rgb_list), rank, world)
     rgb_list, label_list = rgb_list[lo:hi], label_list[lo:hi]
     print("num of image:{}".format(len(rgb_list)))
     sd = load_state_dict_file(args.weights)
@@ -228,9 +270,14 @@ def main(argv=None):
             sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
         engine = EspnetEngine(sd, classes=args.classes, p=args.p, q=args.q, encoder_only=True)
     else:
-        engine = EspnetEngine(sd, classes=args.classes, p=args.p, q=args.q)
-    evaluate(args, engine, rgb_list, label_list)
-    engine.close()
+        engine = EspnetEngine(sd, classes=args.classes, p=args.p, q=args.q, lanes=2)
+    try:
+        evaluate(args, engine, rgb_list, label_list, rank, world, dist)
+    finally:
+        engine.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
     return 0
 
 

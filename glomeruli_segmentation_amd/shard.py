@@ -30,6 +30,61 @@ def plan_grid(height, width, tile_h, tile_w):
     return [(y, x) for y in ys for x in xs]
 
 
+def init_from_env(use_gpu=True):
+    """Process-group setup of a CLI started one process per GPU (torchrun, or launch.spawn_ranks): RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* from the environment.  Returns (rank, world, local_rank, dist | None); with one rank nothing is
+    initialised.  Backend "nccl" (RCCL over xGMI) on the GPUs, "gloo" without them; GLOMSEG_DIST_BACKEND overrides (the
+    one-GPU rehearsal of the tests uses gloo with every rank on device 0)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world <= 1:
+        return 0, 1, local, None
+    from .launch import place_rank
+    place_rank()                                   # before the first GPU call
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = os.environ.get("GLOMSEG_DIST_BACKEND") or ("nccl" if use_gpu and torch.cuda.is_available() else "gloo")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local, dist
+
+
+def collective_device(dist, device=None):
+    """the device tensors handed to `dist` must live on: the CPU for gloo, this rank's current GPU otherwise"""
+    import torch
+    if dist is None or dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+
+def gather_rows(rows, rank, world, dist, dst=0):
+    """Per-rank lists (CSV rows, detection boxes: a few KB) -> their concatenation in rank order on `dst`, None elsewhere.
+    Ranks own contiguous ranges, so rank order is the single-process order."""
+    if dist is None or world == 1:
+        return list(rows)
+    parts = [None] * world if rank == dst else None
+    dist.gather_object(list(rows), parts, dst=dst)
+    return [r for part in parts for r in part] if rank == dst else None
+
+
+def reduce_sum_to_all(array, dist, device=None):
+    """element-wise sum over ranks of a small integer / float array (confusion matrix, per-class totals)"""
+    import torch
+    if dist is None:
+        return np.asarray(array)
+    t = torch.from_numpy(np.ascontiguousarray(array)).to(collective_device(dist, device))
+    dist.all_reduce(t)
+    return t.cpu().numpy()
+
+
 def segment_sharded(compute, load_tiles, total, rank, world, dist=None, device=None, batch=32, classes=5,
                     gather_masks=True):
     """Run `compute` over this rank's tile range and do the final exchange.
@@ -58,11 +113,11 @@ def segment_sharded(compute, load_tiles, total, rank, world, dist=None, device=N
     local = torch.cat(masks, 0) if masks else None
     if counts is None:
         counts = torch.zeros(classes, dtype=torch.int64)
-    if world == 1 or dist is None:
+    if dist is None:      # (a process group of one rank still runs the exchange: the nccl test executes it on one GPU)
         return (local.cpu().numpy() if local is not None else None), counts.cpu().numpy()
-    host_staged = dist.get_backend() == "gloo"
-    dev = torch.device("cpu") if host_staged else (
-        torch.device(device) if device is not None else (local.device if local is not None else torch.device("cpu")))
+    # gloo takes host tensors; every other backend (nccl = RCCL) takes tensors on this rank's GPU -- also from a rank whose
+    # range is empty or whose compute returned host arrays
+    dev = collective_device(dist, device)
     tot = counts.to(dev)
     dist.all_reduce(tot)                                   # per-class pixel totals of the whole slide
     out = None

@@ -1129,7 +1129,7 @@ def test_slide_bench_shards_consistently(torch_mod):
     import sys
     from conftest import REPO
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(REPO, "tools", "bench_slide.py"), "--size", "16000"]
+    cmd = [sys.executable, os.path.join(REPO, "tools", "bench_slide.py"), "--size", "40000"]      # BASELINE cfg 4 at its stated size
     one = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run(cmd + ["--gpus", "2"], env=dict(env, GS_BENCH_BACKEND="gloo", GS_BENCH_ONE_GPU="1"), capture_output=True,
@@ -1137,7 +1137,7 @@ def test_slide_bench_shards_consistently(torch_mod):
     assert two.returncode == 0, two.stderr[-2000:]
     a = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     b = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
-    assert a["crops"] == b["crops"] > 0 and a["windows"] == b["windows"] > 0
+    assert a["crops"] == b["crops"] == 56 and a["windows"] == b["windows"] == 36 and a["window_px"] == [1098, 1098]
     assert a["pixel_totals"] == b["pixel_totals"] and a["map_nonzero"] == b["map_nonzero"] > 0
     assert sum(a["pixel_totals"]) > 0
 
@@ -1151,7 +1151,7 @@ def test_ensemble_bench_one_slide_per_rank(torch_mod):
     import sys
     from conftest import REPO
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(REPO, "tools", "bench_ensemble.py"), "--size", "16000", "--slides", "2"]
+    cmd = [sys.executable, os.path.join(REPO, "tools", "bench_ensemble.py"), "--size", "40000", "--slides", "8"]   # cfg 5 as stated
     one = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run(cmd + ["--gpus", "2"], env=dict(env, GS_BENCH_BACKEND="gloo", GS_BENCH_ONE_GPU="1"), capture_output=True,
@@ -1159,7 +1159,173 @@ def test_ensemble_bench_one_slide_per_rank(torch_mod):
     assert two.returncode == 0, two.stderr[-2000:]
     a = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     b = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
-    assert a["pixel_totals_per_slide"] == b["pixel_totals_per_slide"] and len(a["pixel_totals_per_slide"]) == 2
-    assert a["crops_per_slide"] == b["crops_per_slide"] > 0 and a["folds"] == 5
+    assert a["pixel_totals_per_slide"] == b["pixel_totals_per_slide"] and len(a["pixel_totals_per_slide"]) == 8
+    assert a["crops_per_slide"] == b["crops_per_slide"] == 56 and a["folds"] == 5
     assert all(sum(row) > 0 for row in a["pixel_totals_per_slide"])
     assert a["pixel_totals_per_slide"][0] != a["pixel_totals_per_slide"][1]        # the slides differ (seeded per slide)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the five stages chained through FILES, as the reference chains its scripts
+def test_cli_chain_detect_merge_crop_segment_composite(torch_mod, tmp_path):
+    """python -m ...detect (PNG branch, synthetic detector weights) -> python -m ...merge -> level-0 crops named as
+    make_seg_data.py:360 names them -> python -m ...segment -> python -m ...composite, every hand-over a file on disk;
+    the composited 1/8 map equals the oracle's window walk over the class maps the segment step wrote"""
+    import json
+    from PIL import Image
+    from conftest import GOLDEN
+    from glomeruli_segmentation_amd import composite, detect, merge, segment
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    from oracle import image_oracle as io
+    W, H, ds, mpp = 9600, 7300, 8.0, 0.5                   # not a multiple of 2400 high: a partial bottom window
+    data_dir = tmp_path / "kidney" / "site_a"
+    sdir = data_dir / "02_PAS" / "H16-0001"
+    sdir.mkdir(parents=True)
+    small = np.ascontiguousarray(synth_tile(9, int(H / ds), int(W / ds), blobs=8)[:, :, ::-1])       # RGB slide at 1/8
+    Image.fromarray(small).save(sdir / "H16-0001_PAS.PNG")
+    tl = tmp_path / "target_list.txt"
+    tl.write_text("H16-0001/H16-0001_PAS,%d,%d,40,%g,%g,%g\n" % (W, H, ds, mpp, mpp))
+    out = tmp_path / "output"
+    # 1. detect
+    assert detect.main(["--target_list", str(tl), "--data_dir", str(data_dir) + "/", "--staining", "OPT_PAS", "--output_dir",
+                        str(out / "detect"), "--window_size", "2000", "--overlap_ratio", "0.1", "--conf_threshold", "0.3",
+                        "--synthetic_weights", "0", "--batch", "8"]) == 0
+    det_csv = out / "detect" / "OPT_PAS_GlomusList.csv"
+    n_rows = len(open(det_csv).read().splitlines())
+    plan = detect.plan_windows(W, H, mpp, mpp, ds, 2000, 0.1, from_image=True)
+    assert n_rows > 0 and len(open(out / "detect" / "OPT_PAS_GlomusList_log.csv").read().splitlines()) == 2
+    # 2. merge
+    assert merge.main(["--staining", "OPT_PAS", "--target_list", str(tl), "--detected_list", str(det_csv), "--output_dir", str(out / "detect"),
+                       "--output_file_ext", "t", "--conf_threshold", "0.3", "--overlap_threshold", "0.35"]) == 0
+    merged_csv = out / "detect" / "OPT_PAS_GlomusMergedList_t.csv"
+    boxes, order = merge.read_merged_csv(merged_csv)
+    assert order == ["H16-0001"] and 0 < len(boxes["H16-0001"]) <= n_rows
+    # 3. crops (make_seg_data.py:357-361 reads them from the slide at level 0; here: the 1/8 slide blown up, a stand-in for
+    #    OpenSlide) -- the first few boxes of a usable size, the rest stay without a segmentation (the compositor skips them)
+    use = [b for b in boxes["H16-0001"] if 64 <= b[2] - b[0] <= 2000 and 64 <= b[3] - b[1] <= 2000 and b[0] >= 0 and b[1] >= 0
+           and b[2] <= W and b[3] <= H][:6]
+    assert len(use) >= 2
+    cdir = out / "seg" / "org_image" / "H16-0001"
+    cdir.mkdir(parents=True)
+    for b in use:
+        ys = np.clip((b[1] + np.arange(b[3] - b[1])) // 8, 0, small.shape[0] - 1)
+        xs = np.clip((b[0] + np.arange(b[2] - b[0])) // 8, 0, small.shape[1] - 1)
+        Image.fromarray(small[ys][:, xs]).save(cdir / (merge.crop_name(b) + ".PNG"))
+    # 4. segment
+    mean, std = FOLD_MEAN_STD[1]
+    assert segment.main(["--rgb_data_dir", str(out / "seg" / "org_image"), "--savedir", str(out / "seg" / "results"), "--weights",
+                         os.path.join(GOLDEN, "weights_fold1.npz"), "--gpu_id", "0", "--mean", *[str(v) for v in mean], "--std",
+                         *[str(v) for v in std], "--cityFormat", "--batch", "4"]) == 0
+    names = sorted(set(merge.crop_name(b) for b in use))
+    pix = open(out / "seg" / "results" / "summary_pixel.csv").read().splitlines()
+    assert len(pix) == 1 + len(names)
+    j = json.load(open(out / "seg" / "results" / "H16-0001" / (names[0] + ".json")))
+    assert j["imagePath"] == names[0] + ".PNG" and j["imageData"] and j["classMapPath"] == names[0] + "_classmap.png"
+    # 5. composite
+    assert composite.main(["--staining", "OPT_PAS", "--merged_detection_result_csv", str(merged_csv), "--target_list", str(tl), "--wsi_dir",
+                           str(data_dir / "02_PAS"), "--segmentation_pred_json_dir", str(out / "seg" / "results"), "--output_dir",
+                           str(out / "wsi")]) == 0
+    got = np.asarray(Image.open(out / "wsi" / "H16-0001_pred_classmap.png"))
+    assert (out / "wsi" / "H16-0001_pred.jpg").exists()
+    maps, bxs, seen = [], [], set()
+    for b in boxes["H16-0001"]:
+        n = merge.crop_name(b)
+        f = out / "seg" / "results" / "H16-0001" / (n + "_classmap.png")
+        if f.exists() and (b[3] - b[1], b[2] - b[0]) == np.asarray(Image.open(f)).shape:
+            maps.append(composite.relabel(np.asarray(Image.open(f))))
+            bxs.append(tuple(b[:4]))
+    ref = io.reference_wsi_pred_map(maps, bxs, W, H)
+    assert got.shape == ref.shape == (int(H / 8), int(W / 8)) and np.array_equal(got, ref)
+    assert int((got > 0).sum()) > 0
+
+
+def test_segment_cli_two_ranks_write_one_set_of_files(torch_mod, tmp_path):
+    """the segment CLI started as two ranks (on this one GPU: gloo, both on device 0) writes, from rank 0, the summary files a
+    single process writes -- same rows in the same order, one confusion matrix -- and no per-rank partial files"""
+    import subprocess
+    import sys
+    from PIL import Image
+    from conftest import GOLDEN, REPO
+    from glomeruli_segmentation_amd import launch
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    mean, std = FOLD_MEAN_STD[1]
+    rng = np.random.default_rng(11)
+    for pat, sizes in (("PAS-001", [(64, 128), (90, 70)]), ("PAS-002", [(64, 128), (120, 200), (75, 75)])):
+        d, lab = tmp_path / "org" / pat, tmp_path / "lab" / pat
+        d.mkdir(parents=True)
+        lab.mkdir(parents=True)
+        for k, (h, w) in enumerate(sizes):
+            name = "xmin%d_ymin0_xmax%d_ymax%d.PNG" % (k, k + w // 8, h // 8)
+            Image.fromarray(synth_tile(30 + k + len(pat) + h, h, w, blobs=3)[:, :, ::-1]).save(d / name)
+            Image.fromarray(rng.integers(0, 5, (h, w)).astype(np.uint8)).save(lab / name)
+    args = ["--rgb_data_dir", str(tmp_path / "org"), "--label_data_dir", str(tmp_path / "lab"), "--weights", os.path.join(GOLDEN, "weights_fold1.npz"),
+            "--gpu_id", "0", "--inWidth", "128", "--inHeight", "64", "--mean", *[str(v) for v in mean], "--std", *[str(v) for v in std],
+            "--overlay", "--batch", "2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "glomeruli_segmentation_amd.segment"]
+    one = subprocess.run(cmd + args + ["--savedir", str(tmp_path / "one")], env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    os.environ.update(GLOMSEG_DIST_BACKEND="gloo", GLOMSEG_ONE_GPU="1")
+    try:
+        import io as _io
+        err = _io.StringIO()
+        cwd = os.getcwd()
+        os.chdir(REPO)
+        rc = launch.spawn_ranks(cmd, args + ["--savedir", str(tmp_path / "two")], 2, out=_io.StringIO(), err=err)
+        os.chdir(cwd)
+    finally:
+        os.environ.pop("GLOMSEG_DIST_BACKEND")
+        os.environ.pop("GLOMSEG_ONE_GPU")
+    assert rc == 0, err.getvalue()[-2000:]
+    for f in ("summary_pixel.csv", "summary_accuracy.csv", "summary_dataset.csv", "overall_accuracy.txt"):
+        assert open(tmp_path / "one" / f).read() == open(tmp_path / "two" / f).read(), f
+    assert len(open(tmp_path / "two" / "summary_pixel.csv").read().splitlines()) == 6
+    assert not [f for f in os.listdir(tmp_path / "two") if ".rank" in f]
+    assert sorted(os.listdir(tmp_path / "two" / "combined_images" / "PAS-002")) == sorted(os.listdir(tmp_path / "one" / "combined_images" / "PAS-002"))
+    comb = Image.open(tmp_path / "two" / "combined_images" / "PAS-001" / "xmin1_ymin0_xmax9_ymax11.png")
+    assert comb.size == (3 * 70, 90)                        # original | ground truth | prediction (:215-231)
+
+
+def test_sharded_gather_over_rccl_world_of_one(torch_mod, engine1, tmp_path):
+    """shard.segment_sharded with the nccl backend (= RCCL) in a process group of ONE rank: the device-side all_reduce and
+    gather of the masks execute on the GPU (what the 8-GPU job does between GPUs)"""
+    import subprocess
+    import sys
+    from conftest import REPO
+    script = tmp_path / "w.py"
+    script.write_text("""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %r)
+from glomeruli_segmentation_amd import shard
+from glomeruli_segmentation_amd.engine import EspnetEngine
+from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+z = np.load(os.path.join(%r, "tests", "golden", "weights_fold1.npz"))
+eng = EspnetEngine({k: z[k] for k in z.files})
+mean, std = FOLD_MEAN_STD[1]
+tiles = np.stack([synth_tile(70 + i, 64, 128, blobs=3) for i in range(5)])
+def compute(t):
+    m, h, _ = eng.segment(torch.from_numpy(t).cuda(), mean, std)
+    return m, h
+masks, counts = shard.segment_sharded(compute, lambda lo, hi: tiles[lo:hi], 5, 0, 1, dist=dist, batch=2)
+ref, rh, _ = eng.segment(torch.from_numpy(tiles).cuda(), mean, std)
+assert np.array_equal(masks, ref.cpu().numpy()) and np.array_equal(counts, rh.sum(0).cpu().numpy())
+# the exchange itself, as rank 0 of a group of one: all_reduce + gather of device tensors
+dev = shard.collective_device(dist)
+assert dev.type == "cuda"
+t = rh.sum(0).to(dev)
+dist.all_reduce(t)
+buf = ref.to(dev)
+recv = [torch.empty_like(buf)]
+dist.gather(buf, recv, dst=0)
+assert torch.equal(recv[0], ref) and torch.equal(t.cpu(), rh.sum(0).cpu())
+dist.destroy_process_group()
+print("ok")
+""" % (REPO, REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-3000:]

@@ -105,7 +105,7 @@ dist.init_process_group("gloo", rank=rank, world_size=world)
 z = np.load(os.path.join(os.environ["GS_REPO"], "tests", "golden", "weights_fold1.npz"))
 sd = {k: z[k] for k in z.files}
 mean, std = FOLD_MEAN_STD[1]
-TOTAL = 5
+TOTAL = int(os.environ.get("GS_TOTAL", "5"))
 
 def load(lo, hi):
     return np.stack([synth_tile(100 + i, 32, 64, blobs=2) for i in range(lo, hi)])
@@ -147,6 +147,14 @@ def test_two_rank_sharding_equals_single_process(tmp_path):
                                     5, 0, 1)
     assert np.array_equal(got["masks"], masks) and np.array_equal(got["counts"], counts)
     assert counts.sum() == 5 * 32 * 64
+    # more ranks than tiles: rank 0's range is empty (rank_range(1, 0, 2) == (0, 0)); the exchange still completes
+    out1 = tmp_path / "out1.npz"
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), GS_TOTAL="1", GS_OUT=str(out1), MASTER_PORT="29619"))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got1 = np.load(out1)
+    assert np.array_equal(got1["masks"], masks[:1]) and np.array_equal(got1["counts"], np.bincount(masks[0].ravel(), minlength=5))
 
 
 def test_bench_spawns_one_process_per_gpu():
@@ -460,3 +468,148 @@ def test_cabi_argument_and_device_errors_without_gpu(sd1):
         from glomeruli_segmentation_amd.engine import EspnetEngine
         with pytest.raises(RuntimeError):
             EspnetEngine(sd1)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: fail fast, CPU placement
+def test_a_failing_rank_takes_the_job_down_quickly():
+    """`bench.py --gpus 2 --dry-run --fail-rank 1`: rank 1 exits with code 3 after the rendezvous while rank 0 sits in a
+    collective; the parent terminates rank 0, reports rank 1's stderr tail and returns non-zero within seconds"""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run",
+                        "--fail-rank", "1"], env=env, capture_output=True, text=True, timeout=120)
+    el = time.time() - t0
+    assert p.returncode == 3, (p.returncode, p.stderr[-1000:])
+    assert el < 10.0, el
+    assert "rank 1 of 2 exited with code 3" in p.stderr and "fails on purpose" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]      # no result line from a broken job
+
+
+def test_rank_cpu_placement_follows_the_gpu_numa_node(tmp_path):
+    """launch.rank_cpus on a fake sysfs: four GPUs, two per NUMA node; ranks share their node's allowed CPUs evenly"""
+    from glomeruli_segmentation_amd import launch
+    sysfs = tmp_path / "sys"
+    nodes = sysfs / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    (nodes / "0").mkdir(parents=True)
+    (nodes / "0" / "properties").write_text("cpu_cores_count 16\nsimd_count 0\n")
+    for k, (bus, numa) in enumerate([(0x05, 0), (0x15, 0), (0x85, 1), (0x95, 1)]):
+        d = nodes / str(k + 1)
+        d.mkdir()
+        d.joinpath("properties").write_text("simd_count 1024\nlocation_id %d\ndomain 0\n" % (bus << 8))
+        pci = sysfs / "bus" / "pci" / "devices" / ("0000:%02x:00.0" % bus)
+        pci.mkdir(parents=True)
+        pci.joinpath("numa_node").write_text("%d\n" % numa)
+    for n, cl in ((0, "0-7,16-23"), (1, "8-15,24-31")):
+        d = sysfs / "devices" / "system" / "node" / ("node%d" % n)
+        d.mkdir(parents=True)
+        d.joinpath("cpulist").write_text(cl + "\n")
+    assert launch.gpu_numa_nodes(str(sysfs)) == [0, 0, 1, 1]
+    allowed = set(range(32))
+    got = [launch.rank_cpus(r, 4, allowed, str(sysfs)) for r in range(4)]
+    assert got[0] == [0, 1, 2, 3, 4, 5, 6, 7] and got[1] == [16, 17, 18, 19, 20, 21, 22, 23]
+    assert got[2] == [8, 9, 10, 11, 12, 13, 14, 15] and got[3] == [24, 25, 26, 27, 28, 29, 30, 31]
+    # a cgroup that allows only part of a node; no topology at all -> even split of what is allowed
+    assert launch.rank_cpus(1, 4, set(range(0, 20)), str(sysfs)) == [6, 7, 16, 17, 18, 19]      # node 0 within the cgroup: 0-7,16-19
+    assert [launch.rank_cpus(r, 2, set(range(6)), str(tmp_path / "none")) for r in range(2)] == [[0, 1, 2], [3, 4, 5]]
+    assert launch.rank_cpus(0, 1, {3, 4}, str(sysfs)) == [3, 4]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# detector / merge command lines (detect_glomus_test.py:385-456,93-159,196-234; merge_overlaped_glomus.py:385-389)
+def _png_slide_tree(tmp_path, W=53248, H=23040, ds=8.0, mpp=0.2277):
+    """data_dir/<staining dir>/<specimen>/<file>.PNG = a slide at 1/ds, plus its target-list line"""
+    from PIL import Image
+    from glomeruli_segmentation_amd.synth import synth_tile
+    data_dir = tmp_path / "kidney" / "site_a"
+    sdir = data_dir / "02_PAS" / "H16-0001"
+    sdir.mkdir(parents=True)
+    img = synth_tile(9, int(H / ds), int(W / ds), blobs=8)[:, :, ::-1]
+    Image.fromarray(np.ascontiguousarray(img)).save(sdir / "H16-0001_PAS.PNG")
+    tl = tmp_path / "target_list.txt"
+    tl.write_text("#H16-0000/H16-0000_PAS,1,1,40,8,0.2,0.2\nH16-0001/H16-0001_PAS,%d,%d,40,%g,%g,%g\nH16-0404/missing,1,1,40,8,0.2,0.2\n"
+                  % (W, H, ds, mpp, mpp))
+    return str(data_dir) + "/", str(tl), np.ascontiguousarray(img)
+
+
+def test_detect_cli_png_branch_with_a_stub_detector(tmp_path):
+    """parser + target list + window walk over a PNG slide + CSV / log files, with a stub behind the detect_box contract"""
+    from glomeruli_segmentation_amd import detect
+    data_dir, tl, img = _png_slide_tree(tmp_path)
+    seen = []
+
+    def stub(ims):
+        ims = np.asarray(ims)
+        seen.append(ims.shape)
+        n = len(ims)
+        b = np.zeros((n, 2, 4), np.float32)
+        b[:, 0] = [0.25, 0.5, 0.5, 0.75]                      # ymin, xmin, ymax, xmax
+        b[:, 1] = [0.0, 0.0, 0.1, 0.1]
+        s = np.tile(np.array([[0.9, 0.3]], np.float32), (n, 1))
+        return b, s, np.ones_like(s), np.full((n,), 2.0, np.float32)
+
+    out_dir = tmp_path / "out" / "detect"
+    rc = detect.main(["--target_list", tl, "--data_dir", data_dir, "--staining", "OPT_PAS", "--output_dir", str(out_dir),
+                      "--window_size", "2000", "--overlap_ratio", "0.1", "--conf_threshold", "0.6", "--batch", "1"], detector=stub)
+    assert rc == 0
+    plan = detect.plan_windows(53248, 23040, 0.2277, 0.2277, 8.0, 2000, 0.1, from_image=True)
+    assert (plan.x_split_times, plan.y_split_times, plan.window_x) == (7, 3, 1098)
+    assert len(seen) == 21 and all(sh == (1, 1098, 1098, 3) for sh in seen)
+    rows = open(out_dir / "OPT_PAS_GlomusList.csv").read().splitlines()
+    assert len(rows) == 21                                   # one box per window passes the threshold
+    f = rows[0].split(",")
+    assert f[:4] == ['"site_a"', '"H16-0001"', '"H16-0001_PAS.PNG"', 'new']
+    # window (0,0): x1 = 0*8 + int(1098*0.5)*8, y1 = int(1098*0.25)*8 (:234, :319-325)
+    assert [float(v) for v in f[5:9]] == [549 * 8.0, 274 * 8.0, 823 * 8.0, 549 * 8.0] and f[9] == "0.9"
+    last = rows[-1].split(",")                                # window (6,2): origin = stride * index, lifted by the downsample
+    assert float(last[5]) == plan.step_x * 6 * 8.0 + 549 * 8.0 and float(last[6]) == plan.step_y * 2 * 8.0 + 274 * 8.0
+    log = open(out_dir / "OPT_PAS_GlomusList_log.csv").read().splitlines()
+    assert log[0] == "file,time" and len(log) == 2 and log[1].startswith('"H16-0001_PAS",')
+    # windows past the right / bottom edge are padded with black, as PIL's crop pads them
+    with pytest.raises(ValueError):
+        detect.staining_type("OPT_XYZ")
+    assert detect.staining_dir("OPT_HE") == "" and detect.staining_dir("OPT_PAM") == "03_PAM"
+    # defaults (500 um, 0.5) when --window_size is absent (:52-54)
+    seen.clear()
+    detect.main(["--target_list", tl, "--data_dir", data_dir, "--staining", "OPT_PAS", "--output_dir", str(out_dir), "--output_file_ext",
+                 "_default", "--batch", "64"], detector=stub)
+    p2 = detect.plan_windows(53248, 23040, 0.2277, 0.2277, 8.0, None, None, from_image=True)
+    assert sum(sh[0] for sh in seen) == p2.x_split_times * p2.y_split_times == 49 * 21
+    assert os.path.isfile(out_dir / "OPT_PAS_default.csv")
+    # a .pb graph is refused with an explanation; a missing file likewise
+    (tmp_path / "m").mkdir()
+    (tmp_path / "m" / "frozen_inference_graph.pb").write_bytes(b"x")
+    with pytest.raises(ValueError, match="frozen graph"):
+        detect.load_detector(str(tmp_path / "m"), "frozen_inference_graph.pb")
+    with pytest.raises(FileNotFoundError):
+        detect.load_detector(str(tmp_path / "nope"), "frozen_inference_graph.pb")
+
+
+def test_merge_cli(tmp_path):
+    """merge_overlaped_glomus.py's command line: detections CSV + target list -> merged CSV + log"""
+    from glomeruli_segmentation_amd import merge
+    z = load_golden("merge.npz")
+    dets = z["in_0"]
+    det_csv = tmp_path / "OPT_PAS_GlomusList.csv"
+    with open(det_csv, "w") as f:
+        for d in dets:
+            f.write('"site_a","H16-0001","H16-0001_PAS.PNG",new,2020-01-01T00:00:00,%s,%s,%s,%s,%s\n' % tuple(str(float(v)) for v in d[:5]))
+    tl = tmp_path / "tl.txt"
+    tl.write_text("H16-0001/H16-0001_PAS,53248,23040,40,8,0.2277,0.2277\n")
+    rc = merge.main(["--staining", "OPT_PAS", "--target_list", str(tl), "--detected_list", str(det_csv), "--output_dir", str(tmp_path),
+                     "--output_file_ext", "test", "--conf_threshold", "0.2", "--overlap_threshold", "0.35"])
+    assert rc == 0
+    rows = open(tmp_path / "OPT_PAS_GlomusMergedList_test.csv").read().splitlines()
+    want = merge.merge_detections([list(map(float, d[:5])) for d in dets], 0.2277, 0.2277, 0.35, 0.2)
+    assert rows == [r.rstrip("\n") for r in merge.merged_csv_rows("site_a", "H16-0001", "H16-0001_PAS.PNG", want)]
+    log = open(tmp_path / "OPT_PAS_GlomusMergedList_test_log.csv").read().splitlines()
+    assert len(log) == 1 and log[0].startswith('"H16-0001_PAS.PNG",')
+    boxes, order = merge.read_merged_csv(tmp_path / "OPT_PAS_GlomusMergedList_test.csv")
+    assert order == ["H16-0001"] and len(boxes["H16-0001"]) == len(want)
+    # a non-PNG slide without OpenSlide and without a target-list line fails loudly
+    with open(det_csv, "w") as f:
+        f.write('"site_a","H16-0002","H16-0002_PAS.ndpi",new,2020-01-01T00:00:00,0.0,0.0,100.0,100.0,0.9\n')
+    with pytest.raises(RuntimeError, match="openslide"):
+        merge.main(["--staining", "OPT_PAS", "--target_list", str(tl), "--detected_list", str(det_csv), "--output_dir", str(tmp_path),
+                    "--overlap_threshold", "0.35"])
