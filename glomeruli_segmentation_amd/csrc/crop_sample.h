@@ -29,16 +29,30 @@ __device__ __forceinline__ void linear_tap(int d, double scale, int n, int &i0, 
 // OpenCV's own expression for the scale: 1. / inv_scale with inv_scale = (double)dst / src
 __device__ __forceinline__ double cv_inv_scale(int dst, int src) { return 1.0 / ((double)dst / (double)src); }
 
-// One output value of channel c: the four normalised taps ((x - mean) / std, two fp32 roundings as numpy does them),
-// the horizontal blend of each row, the vertical blend, /255.  Every product and sum is rounded on its own (no fused
-// multiply-add), as the two-pass CPU implementations round them.
+// (x - mean) / std of one uint8 value, two fp32 roundings as numpy does them (VisualizeResults_iou.py:109,111).  The kernels
+// tabulate it once per workgroup (3 x 256 entries in LDS): the same bits as computing it per tap, without the IEEE
+// divisions -- 48 per output pixel group -- that made the resampling kernels VALU-bound.
+__device__ __forceinline__ float crop_norm(int b, float mean, float stdv)
+{
+#pragma clang fp contract(off)
+    return ((float)b - mean) / stdv;
+}
+__device__ __forceinline__ void crop_norm_table(float (*lut)[256], const float mean[3], const float stdv[3])
+{
+    for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x)
+        lut[i >> 8][i & 255] = crop_norm(i & 255, mean[i >> 8], stdv[i >> 8]);
+    __syncthreads();
+}
+
+// One output value of channel c from the table: the horizontal blend of each row, the vertical blend, /255.  Every product
+// and sum is rounded on its own (no fused multiply-add), as the two-pass CPU implementations round them.
 __device__ __forceinline__ float crop_sample(const unsigned char *src, int w, int c, int x0, int x1, int y0, int y1, float wx, float wy,
-                                             float mean, float stdv)
+                                             const float *lut_c)
 {
 #pragma clang fp contract(off)
     const unsigned char *r0 = src + ((long long)y0 * w) * 3 + c, *r1 = src + ((long long)y1 * w) * 3 + c;
-    const float a00 = ((float)r0[x0 * 3] - mean) / stdv, a01 = ((float)r0[x1 * 3] - mean) / stdv;
-    const float a10 = ((float)r1[x0 * 3] - mean) / stdv, a11 = ((float)r1[x1 * 3] - mean) / stdv;
+    const float a00 = lut_c[r0[x0 * 3]], a01 = lut_c[r0[x1 * 3]];
+    const float a10 = lut_c[r1[x0 * 3]], a11 = lut_c[r1[x1 * 3]];
     const float ux = 1.0f - wx, uy = 1.0f - wy;
     const float top = a00 * ux + a01 * wx;
     const float bot = a10 * ux + a11 * wx;

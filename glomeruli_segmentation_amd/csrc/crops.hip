@@ -37,6 +37,8 @@ struct PrepArgs {
 // one thread = four consecutive output columns of one row, all three channels: 16-byte stores
 __global__ void __launch_bounds__(256) crops_prep_kernel(const CropTable t, const PrepArgs a)
 {
+    __shared__ float lut[3][256];
+    crop_norm_table(lut, a.mean, a.std);
     const int i = blockIdx.y;
     if (a.hist_zero && blockIdx.x == 0 && i == 0)
         for (int k = threadIdx.x; k < a.hist_count; k += 256)
@@ -59,10 +61,10 @@ __global__ void __launch_bounds__(256) crops_prep_kernel(const CropTable t, cons
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float4 v;
-        v.x = crop_sample(src, w, c, x0[0], x1[0], y0, y1, wx[0], wy, a.mean[c], a.std[c]);
-        v.y = crop_sample(src, w, c, x0[1], x1[1], y0, y1, wx[1], wy, a.mean[c], a.std[c]);
-        v.z = crop_sample(src, w, c, x0[2], x1[2], y0, y1, wx[2], wy, a.mean[c], a.std[c]);
-        v.w = crop_sample(src, w, c, x0[3], x1[3], y0, y1, wx[3], wy, a.mean[c], a.std[c]);
+        v.x = crop_sample(src, w, c, x0[0], x1[0], y0, y1, wx[0], wy, lut[c]);
+        v.y = crop_sample(src, w, c, x0[1], x1[1], y0, y1, wx[1], wy, lut[c]);
+        v.z = crop_sample(src, w, c, x0[2], x1[2], y0, y1, wx[2], wy, lut[c]);
+        v.w = crop_sample(src, w, c, x0[3], x1[3], y0, y1, wx[3], wy, lut[c]);
         *reinterpret_cast<float4 *>(dst + (long long)c * a.net_h * a.net_w) = v;
     }
 }

@@ -634,6 +634,8 @@ struct CropArgs {
 
 __global__ void __launch_bounds__(256) crop_preprocess_kernel(const CropArgs a)
 {
+    __shared__ float lut[3][256];
+    crop_norm_table(lut, a.mean, a.std);
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.oh * a.ow)
         return;
@@ -644,7 +646,7 @@ __global__ void __launch_bounds__(256) crop_preprocess_kernel(const CropArgs a)
     linear_tap(oy, cv_inv_scale(a.oh, a.h), a.h, y0, y1, wy);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-        a.out[((long long)c * a.oh + oy) * a.ow + ox] = crop_sample(a.src, a.w, c, x0, x1, y0, y1, wx, wy, a.mean[c], a.std[c]);
+        a.out[((long long)c * a.oh + oy) * a.ow + ox] = crop_sample(a.src, a.w, c, x0, x1, y0, y1, wx, wy, lut[c]);
 }
 
 __global__ void __launch_bounds__(256)

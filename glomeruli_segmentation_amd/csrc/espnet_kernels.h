@@ -118,17 +118,35 @@ __device__ __forceinline__ float stem_fetch(const StemArgs &a, const float (*lut
 // Two horizontally adjacent output pixels per thread: the 3x5 input window is fetched once (15 values per channel
 // instead of 18), every weight that arrives in an SGPR feeds two FMAs, and the 19 + 3 results leave as 8-byte stores.
 constexpr int STEM_PX = 2;
+// uint8 input: a thread's window row is 15 consecutive bytes (5 pixels x BGR) that start one byte past a dword boundary
+// (x is even, so byte 6x - 3), i.e. bytes 1..15 of four consecutive dwords: 12 dword loads + 45 bit-field extracts per thread
+// instead of 45 single-byte loads with a 64-bit address, a clamp and a select each -- the kernel was VALU-bound on exactly
+// that bookkeeping (1 935 VALU instructions per wave for 864 FMAs): 0.1227 -> 0.0850 ms per launch at batch 32
+// (profiles/README.md, round 3).  STEM_LUT_COPIES lane-swizzled copies of the table (copy = lane % COPIES; a ds_read_b32
+// banks by (a/4) % 32 within each 32-lane half) were measured on top: 1 copy 0.0850, 8 copies 0.0876, 16 copies 0.1090 ms --
+// the bank conflicts of the data-dependent lookups are not what bounds the kernel, the extra address arithmetic and table
+// fill cost more than they save.  One copy ships.
+#ifndef STEM_DWORD
+#define STEM_DWORD 1
+#endif
+#ifndef STEM_LUT_COPIES
+#define STEM_LUT_COPIES 1
+#endif
 template <bool U8>
 __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
 {
-    __shared__ float lut[3][256];
+    constexpr int NC = (U8 && STEM_DWORD) ? STEM_LUT_COPIES : 1;
+    __shared__ float lut[3][256 * NC];
     if (U8) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float v = (float)threadIdx.x;
             v = v - a.mean[c];
             v = v / a.std[c];
-            lut[c][threadIdx.x] = v / 255.0f;
+            v = v / 255.0f;
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                lut[c][threadIdx.x * NC + k] = v;
         }
         __syncthreads();
     }
@@ -146,13 +164,74 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a)
     const bool two = x + 1 < W1;
 
     float v[3][3][2 * STEM_PX + 1];
+    if (U8 && STEM_DWORD) {
+        // rows 2y-1 .. 2y+1, bytes [6x-4, 6x+12) of each (W is a multiple of 8: rows start dword-aligned and the last
+        // thread of a row ends exactly at the row's end)
+        const unsigned char *img = static_cast<const unsigned char *>(a.in) + (long long)n * a.H * a.W * 3;
+        const int cp = (threadIdx.x & (NC - 1));
+        unsigned d[3][4];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = min(max(2 * y - 1 + ky, 0), a.H - 1);
+            const unsigned *row = reinterpret_cast<const unsigned *>(img + (long long)yy * a.W * 3) + (x > 0 ? (6 * x - 4) / 4 : 0);
+            // (unaligned-to-16 but dword-aligned: four dword loads the compiler may merge)
+            d[ky][0] = row[0];
+            d[ky][1] = row[1];
+            d[ky][2] = row[2];
+            d[ky][3] = row[3];
+            if (x == 0) {   // no column -1: the row was fetched from its first byte, one dword further right
+                d[ky][3] = d[ky][2];
+                d[ky][2] = d[ky][1];
+                d[ky][1] = d[ky][0];
+                d[ky][0] = 0u;
+            }
+        }
+        const bool top = y == 0, left = x == 0;   // the only padding a window can meet (H, W even; x even)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 2 * STEM_PX + 1; ++kx)
-                v[c][ky][kx] = stem_fetch<U8>(a, lut, n, c, 2 * y - 1 + ky, 2 * x - 1 + kx);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int pos = 1 + kx * 3 + c;                       // byte 1..15 of the 16
+                    const unsigned b = (d[ky][pos >> 2] >> (8 * (pos & 3))) & 0xffu;
+                    float t = lut[c][b * NC + cp];
+                    if ((ky == 0 && top) || (kx == 0 && left))
+                        t = 0.0f;                                          // padding acts on the normalised tensor
+                    v[c][ky][kx] = t;
+                }
+    } else if (!U8 && STEM_DWORD) {
+        // fp32 NCHW input (the tensor the crop pipeline resamples into): five consecutive floats per window row and channel,
+        // the same bookkeeping-free form -- only the top row and the left column can be padding
+        const float *img = static_cast<const float *>(a.in) + (long long)n * 3 * a.H * a.W;
+        const bool top = y == 0, left = x == 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = max(2 * y - 1 + ky, 0);
+                const float *row = img + ((long long)c * a.H + yy) * a.W + (left ? 0 : 2 * x - 1);
+                float r[5];
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx)
+                    r[kx] = row[kx];          // (x == 0: columns 0..4, one further right; W >= 8)
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    float t = left ? (kx > 0 ? r[kx - 1] : 0.0f) : r[kx];
+                    if (ky == 0 && top)
+                        t = 0.0f;
+                    v[c][ky][kx] = t;
+                }
+            }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 2 * STEM_PX + 1; ++kx)
+                    v[c][ky][kx] = stem_fetch<U8>(a, reinterpret_cast<const float(*)[256]>(&lut[0][0]), n, c, 2 * y - 1 + ky, 2 * x - 1 + kx);
+    }
 
     // all arithmetic first, all stores last: a store between two weight reads would force hipcc to
     // re-read the (possibly aliasing) weights from memory with vector loads and a full wait each time

@@ -5,7 +5,7 @@ tag=$1; shift
 mkdir -p gpurun_out
 run() {
     name=$1; lib=$2
-    GLOMSEG_EXPERIMENT=1 GLOMSEG_ALLOW_DIAG=1 GLOMSEG_LIB=$lib timeout -k 10 300 python bench.py --steps 20 --warmup 3 --repeats 3 --no-cpu-baseline --no-host-pipeline > gpurun_out/ab_${tag}_$name.json 2> gpurun_out/ab_${tag}_$name.err || { echo "variant $name failed"; tail -5 gpurun_out/ab_${tag}_$name.err; return 1; }
+    GLOMSEG_EXPERIMENT=1 GLOMSEG_ALLOW_DIAG=1 GLOMSEG_LIB=$lib timeout -k 10 300 python bench.py --steps 20 --warmup 3 --repeats 3 --no-cpu-baseline --no-host-pipeline --no-real-crops > gpurun_out/ab_${tag}_$name.json 2> gpurun_out/ab_${tag}_$name.err || { echo "variant $name failed"; tail -5 gpurun_out/ab_${tag}_$name.err; return 1; }
     python - "$name" gpurun_out/ab_${tag}_$name.json <<'PY'
 import json,sys
 j=json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])

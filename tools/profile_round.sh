@@ -9,7 +9,7 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 # one batch in flight under the profiler: with two, co-running kernels stretch each other's durations in the trace
-B="python3 bench.py --steps 20 --warmup 3 --repeats 1 --lanes 1 --no-cpu-baseline --no-host-pipeline"
+B="python3 bench.py --steps 20 --warmup 3 --repeats 1 --lanes 1 --no-cpu-baseline --no-host-pipeline --no-real-crops"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- $B > $out/bench_under_rocprof.json 2> $out/stats.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- $B > /dev/null 2> $out/fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- $B > /dev/null 2> $out/write.err || exit 1
