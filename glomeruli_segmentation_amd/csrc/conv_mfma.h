@@ -198,6 +198,11 @@ constexpr int F_RES_RING = 524288;   // residual values through a half-slot regi
 // so that neighbouring tasks (neighbouring waves of one workgroup) ask for the shared row at the same moment -- the end of
 // the even row's k-loop, and of the odd row's -- instead of a whole task apart, when it has long left the caches.
 constexpr int F_S2_FLIP = 1048576;
+// Dilated 3x3 branches: the tap row ty of dilation d reads input row y + (ty-1)*d, which for rows within d of the top /
+// bottom edge lies wholly in the zero halo -- a third of that dilation's matrix work multiplying zeros (over a 64-row
+// level-3 map: d16 half of the rows, d8 a quarter, ...: 6.5 % of the branch k-steps).  When a chunk is exactly one tap row
+// (G == NSTEP) such a chunk is skipped (wave-uniform), and the operand ring is refilled with the next LIVE chunk instead.
+constexpr int F_SKIP_PAD = 4194304;
 constexpr int F_X_NOLOAD = 16;  // GS_DIAG timing experiments only (results are garbage): no activation loads in the loop
 constexpr int F_X_NOLDS = 32;   // GS_DIAG: no LDS weight reads in the loop
 constexpr int F_X_NOEPI = 64;   // GS_DIAG: no epilogue at all
@@ -246,6 +251,7 @@ constexpr int conv_min_waves(int MT, int TAPS, int NDIL, int P, int FLAGS)
     return (MT == 16 && TAPS == 9 && NDIL == 5 && P == 4) ? CFG_L2_MINW : 1;
 }
 
+#define M_KL_OF(MT_) (Mfma<MT_>::KL)
 template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int G, int FLAGS>
 __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, FLAGS) * WAVES / 8) conv_mfma_kernel(const ConvArgs a)
 {
@@ -255,6 +261,9 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
     constexpr bool VEC = FLAGS & F_VEC;
     constexpr bool AGL = FLAGS & F_A_GLOBAL, FUSE = FLAGS & F_FUSE1X1;
     constexpr bool S2FLIP = FLAGS & F_S2_FLIP;
+    constexpr bool SKIP = FLAGS & F_SKIP_PAD;
+    static_assert(!SKIP || (TAPS == 9 && STRIDE == 1 && !(FLAGS & (F_S2PAIR | F_XMERGE)) && G * M_KL_OF(MT) == CINP),
+                  "F_SKIP_PAD: unit-stride 3x3 with one tap row per chunk");
     static_assert(!S2FLIP || (STRIDE == 2 && TAPS == 9 && NDIL == 1), "F_S2_FLIP is for the stride-2 3x3 reduce");
     static_assert(kDiag || !(FLAGS & F_X_ALL), "timing / stamp variants exist in -DGS_DIAG builds only");
     constexpr int IAUX = (FLAGS & F_IN_NT) ? 2 : 0;
@@ -351,8 +360,14 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         const int tk = idle ? (a.total_tasks - 1) : task;
         const int n = tk / tasks_per_img;
         const int rem = tk - n * tasks_per_img;
-        const int y = rem / a.strips;
-        const int x0 = (rem - y * a.strips) * XSTEP;
+        // F_SKIP_PAD: rows near the top / bottom edge skip tap rows and finish early, and a wave's tasks are the SAME row of
+        // images `img_stride` apart -- so every other group of images has its rows rotated by half the height (a bijection
+        // per image): a wave then owns one edge row and one middle row, and the saving is spread over all waves
+        const int img_stride = tstride / tasks_per_img > 0 ? tstride / tasks_per_img : 1;
+        const int yrot = SKIP ? a.H / 2 : 0;
+        const int y0r = rem / a.strips;
+        const int y = SKIP && ((n / img_stride) & 1) ? (y0r + yrot >= a.H ? y0r + yrot - a.H : y0r + yrot) : y0r;
+        const int x0 = (rem - y0r * a.strips) * XSTEP;
 
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.in + (long long)n * a.in_sn), 0, a.in_img_bytes, 0x00020000);
@@ -361,10 +376,11 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         const int tn = task + tstride < t1 ? task + tstride : tk;
         const int n_n = tn / tasks_per_img;
         const int rem_n = tn - n_n * tasks_per_img;
-        const int y_n = rem_n / a.strips;
+        const int y0r_n = rem_n / a.strips;
+        const int y_n = SKIP && ((n_n / img_stride) & 1) ? (y0r_n + yrot >= a.H ? y0r_n + yrot - a.H : y0r_n + yrot) : y0r_n;
         const __amdgpu_buffer_rsrc_t rsrc_n = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.in + (long long)n_n * a.in_sn), 0, a.in_img_bytes, 0x00020000);
-        const int sbase_n = (a.in_off + y_n * STRIDE * a.in_pitch + (rem_n - y_n * a.strips) * XSTEP * STRIDE - (XMERGE ? 1 : 0)) * 4;
+        const int sbase_n = (a.in_off + y_n * STRIDE * a.in_pitch + (rem_n - y0r_n * a.strips) * XSTEP * STRIDE - (XMERGE ? 1 : 0)) * 4;
         const bool flip = S2FLIP && (y & 1), flip_n = S2FLIP && (y_n & 1);   // (wave-uniform)
         const __amdgpu_buffer_rsrc_t rout =
             __builtin_amdgcn_make_buffer_rsrc(a.out + (long long)n * a.out_sn, 0, a.out_img_bytes, 0x00020000);
@@ -381,6 +397,13 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
 
         typename M::acc_t acc[P];
         typename M::acc_t acc2[FUSE ? P : 1];   // F_FUSE1X1: the next block's reduced map of this strip
+        // F_SKIP_PAD: chunk c = (dilation c / 3, tap row c % 3) reads input row yy + (ty - 1) << di; the middle row always exists
+        auto chunk_live = [&](int yy, int c) {
+            const int di = c / CPD, ty = c - di * CPD;
+            return ty == 1 || (ty == 0 ? yy >= (1 << di) : yy + (1 << di) < a.H);
+        };
+        const int c_first = SKIP && !chunk_live(y, 0) ? 1 : 0;                 // (wave-uniform)
+        const int c_first_n = SKIP && !chunk_live(y_n, 0) ? 1 : 0;
 
         // per-lane epilogue offsets: lanes beyond the row end get an offset past num_records, which the
         // buffer range check turns into a dropped store / zero load (no exec-mask branches)
@@ -507,7 +530,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                 }
 #pragma unroll
                 for (int tx = 0; tx < TXN; ++tx)
-                    fetch_b(rsrc, sbase, 0, g, tx, flip);
+                    fetch_b(rsrc, sbase, c_first, g, tx, flip);
             }
         }
         if (!staged) {
@@ -546,7 +569,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             for (int g = 0; g < G; ++g)
 #pragma unroll
                 for (int tx = 0; tx < TXN; ++tx)
-                    fetch_a(0, g, tx, flip);
+                    fetch_a(c_first, g, tx, flip);
         }
 
         prefetch_res(0);
@@ -580,12 +603,17 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                 for (int p = 0; p < P; ++p)
                     acc[p] = (typename M::acc_t)(0.0f);
             }
-            // the ring is refilled with the next chunk of this task, or with chunk 0 of the next task
-            const bool last = c + 1 == NCHUNK;
-            const int nx = last ? 0 : c + 1;
+            // the ring is refilled with the next (live) chunk of this task, or with the first one of the next task
+            int nxl = c + 1;
+            if (SKIP)
+                while (nxl < NCHUNK && !chunk_live(y, nxl))
+                    ++nxl;
+            const bool last = nxl >= NCHUNK;
+            const int nx = last ? c_first_n : nxl;
             const __amdgpu_buffer_rsrc_t rs = last ? rsrc_n : rsrc;
             const int sb = last ? sbase_n : sbase;
             const bool fl = last ? flip_n : flip;
+            if (!SKIP || chunk_live(y, c)) {
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -614,6 +642,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                     // chunk, which shrinks the prefetch distance from D steps to a few
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
             if ((FLAGS & F_X_STAMP2) && lane == 0 && task == t0)
                 a.stamp[wg * 64 + 2 + 2 * c] = __builtin_amdgcn_s_memrealtime();
             if ((c + 1) % CPD != 0)

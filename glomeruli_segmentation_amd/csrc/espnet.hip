@@ -106,6 +106,12 @@ constexpr int FUSE_L3 = CFG_FUSE_L3 ? F_FUSE1X1 : 0, FUSE_L2 = CFG_FUSE_L2 ? F_F
 #define CFG_S2_FLIP 3   // bit 0: level-2 stride-2 reduce, bit 1: level-3
 #endif
 constexpr int S2FLIP_L2 = (CFG_S2_FLIP & 1) ? F_S2_FLIP : 0, S2FLIP_L3 = (CFG_S2_FLIP & 2) ? F_S2_FLIP : 0;
+// F_SKIP_PAD (tap rows of a dilated branch that lie wholly in the zero halo are not multiplied): the fused level-3 ESP form,
+// whose chunk is exactly one tap row.  Measured in profiles/README.md (round 3).
+#ifndef CFG_SKIP_PAD
+#define CFG_SKIP_PAD 1
+#endif
+constexpr int SKIP_L3 = CFG_SKIP_PAD ? F_SKIP_PAD : 0;
 
 // Every unit-stride conv launch exists in two pixel mappings; the vector one (F_VEC) needs the output width to be a
 // multiple of P (the 9th configuration parameter).
@@ -750,7 +756,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
                 // and the reduced maps the taps re-read stay in that XCD's 4 MiB L2: beyond-L2 fetch of a launch
                 // 542 -> 296 MB, 0.1898 -> 0.1834 ms (profiles/README.md).
                 if (ca.W % 2 == 0 && !no_vec())
-                    return launch_conv_mfma<CFG_L3_BR_P2R, F_BNACT | F_RES | F_RES_RING | F_VEC | POL_L3_ESP | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+                    return launch_conv_mfma<CFG_L3_BR_P2R, F_BNACT | F_RES | F_RES_RING | F_VEC | POL_L3_ESP | AGL_L3 | FUSE_L3 | SKIP_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
                 return launch_conv_mfma<CFG_L3_BR_P2F, F_BNACT | F_RES | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
             }
             // four consecutive pixels per lane and 16-byte accesses when the width allows it (0.170 ms per
