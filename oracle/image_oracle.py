@@ -7,6 +7,13 @@ cv2 is not installed in this image, so the two ``cv2.resize`` calls of the refer
 OpenCV's sampling rules and PINNED against an independent implementation: tests/golden/resize.npz holds the outputs
 of torch.nn.functional.interpolate (bilinear, align_corners=False, antialias=False = the same half-pixel rule;
 nearest = floor(dst * scale)) on fixed inputs, written by tests/golden/make_golden_resize.py.
+
+One case where OpenCV itself takes another route: for an exact 2x down-scale in both directions (e.g. a 2048x1024 crop to
+1024x512) cv2.resize silently switches INTER_LINEAR to its INTER_AREA code (resize.cpp: `if (interpolation == INTER_LINEAR
+&& is_area_fast && iscale_x == 2 && iscale_y == 2) interpolation = INTER_AREA`).  The result is mathematically the same --
+both are the mean of the 2x2 block, the bilinear taps being 0.5 / 0.5 there -- but the area code sums the four values and
+multiplies by 0.25 where the linear code blends rows then columns, so the last bit can differ.  This restatement (and the GPU
+kernels) use the linear form everywhere; with cv2 absent neither rounding order can be pinned.
 """
 import numpy as np
 

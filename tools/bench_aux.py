@@ -118,6 +118,34 @@ def main():
     t = timeit(lambda: comp.paste(big, 12345, 23456))
     out["cfg4_compositor_paste_1098sq"] = {"us": round(t * 1e6, 1)}
 
+    # ---- cfg 4: the batched crop entry (gs_espnet_segment_crops, device-resident): 32 crops of the example slide's sizes
+    z1 = np.load(os.path.join(REPO, "tests", "golden", "weights_fold1.npz"))
+    eng1 = EspnetEngine({kk: z1[kk] for kk in z1.files})
+    ex = np.load(os.path.join(REPO, "tests", "golden", "merge.npz"))["example_boxes"]
+    sizes = [(int(b[3] - b[1]), int(b[2] - b[0])) for b in ex] + [(int(b[3] - b[1]), int(b[2] - b[0])) for b in ex[:4]]
+    descs, ioff, ooff = [], 0, 0
+    for (hh, ww) in sizes:
+        d = _lib.CropDesc()
+        d.in_off, d.out_off, d.h, d.w, d.x1, d.y1 = ioff, ooff, hh, ww, 8 * (ioff % 4000), 8 * (ooff % 3000)
+        descs.append(d)
+        ioff += hh * ww * 3
+        ooff += (hh * ww + 255) // 256 * 256
+    packed = torch.randint(0, 256, (ioff,), dtype=torch.uint8, device=dev)
+    pout = torch.empty(ooff, dtype=torch.uint8, device=dev)
+    from glomeruli_segmentation_amd.composite import SlideCompositor as SC
+    comp2 = SC(40000, 40000, dev)
+    pt = comp2.paste_target()
+    t_all = timeit(lambda: eng1.segment_crops_resident(packed, descs, mean, std, 512, 1024, packed_out=pout, paste=pt), reps=10)
+    tiles32 = torch.from_numpy(np.stack([synth_tile(i) for i in range(32)])).to(dev)
+    t_u8 = timeit(lambda: eng1.segment(tiles32, mean, std), reps=10)
+    out["cfg4_batched_crop_entry_32_crops"] = {
+        "ms_per_batch": round(t_all * 1e3, 3), "crops/s": round(32 / t_all, 1),
+        "same_engine_uint8_tiles_ms_per_batch": round(t_u8 * 1e3, 3),
+        "overhead_vs_network_sized_uint8_tiles": round(t_all / t_u8, 3),
+        "mean_crop_px": int(np.mean([a * b for a, b in sizes])),
+        "note": "resample 32 crops (example-slide sizes) -> forward -> masks -> resize back + counts -> paste into a 5000 x 5000 map, "
+                "everything resident in HBM, one lane; against the same engine on 32 network-sized uint8 tiles"}
+
     # ---- cfg 5: five-fold ensemble ---------------------------------------------------------------
     engines, mss = [], []
     for f in range(1, 6):
@@ -127,7 +155,9 @@ def main():
     tiles = torch.from_numpy(np.stack([synth_tile(i) for i in range(32)])).to(dev)
     t = timeit(lambda: ensemble_segment(engines, tiles, mss), reps=5, warm=2)
     out["cfg5_ensemble_5fold_batch32"] = {"ms_per_batch": round(t * 1e3, 2), "patches/s": round(32 / t, 1),
-                                          "model_passes/s": round(5 * 32 / t, 1)}
+                                          "model_passes/s": round(5 * 32 / t, 1),
+                                          "single_model_passes/s_same_run_one_lane": round(32 / t_u8, 1),
+                                          "ratio_to_single_model_pass_rate": round(5 * t_u8 / t, 3)}
     print(json.dumps(out, indent=1))
 
 

@@ -86,7 +86,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--size", type=int, default=40000)
-    ap.add_argument("--detector-batch", type=int, default=16)
+    ap.add_argument("--detector-batch", type=int, default=12, help="windows per detector forward (36 windows = 3 x 12: no ragged last batch)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn(args)

@@ -50,7 +50,7 @@ def main():
         if "FETCH_SIZE" in v2 and "WRITE_SIZE" in v2 and not n2.startswith("void at::"):
             # dispatches are over the whole run; per step = per launch x launches per step (8 ESP blocks, 1 otherwise, ...)
             per_step += (2 * v2["FETCH_SIZE"] + v2["WRITE_SIZE"]) * 1024.0 * v2["dispatches"]
-    steps = max(v2["dispatches"] for n2, v2 in k.items() if n2.startswith("stem_kernel"))
+    steps = max(v2["dispatches"] for n2, v2 in k.items() if n2.startswith("stem_kernel<true>") or n2 == "stem_kernel")
     print(json.dumps({
         "kernel": "conv_l3_esp_branches", "kernel_symbol": name, "round": tag, "fused_next_1x1": fused,
         "source": "profiles/%s_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, batch 32)" % tag,
