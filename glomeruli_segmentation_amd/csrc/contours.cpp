@@ -77,42 +77,6 @@ void follow(std::vector<int> &f, int W, int x0, int y0, int from_dir, int nbd, s
     }
 }
 
-double perp_dist2(const Pt &p, const Pt &a, const Pt &b)
-{
-    const double dx = b.x - a.x, dy = b.y - a.y;
-    const double len2 = dx * dx + dy * dy;
-    if (len2 == 0.0) {
-        const double ex = p.x - a.x, ey = p.y - a.y;
-        return ex * ex + ey * ey;
-    }
-    const double cr = dx * (p.y - a.y) - dy * (p.x - a.x);
-    return cr * cr / len2;
-}
-
-void rdp(const std::vector<Pt> &pts, int i0, int i1, double eps2, std::vector<char> &keep)
-{
-    // iterative Ramer-Douglas-Peucker on the open chain pts[i0..i1]
-    std::vector<std::pair<int, int>> st{{i0, i1}};
-    while (!st.empty()) {
-        auto [a, b] = st.back();
-        st.pop_back();
-        double best = -1.0;
-        int bi = -1;
-        for (int i = a + 1; i < b; ++i) {
-            const double d = perp_dist2(pts[i], pts[a], pts[b]);
-            if (d > best) {
-                best = d;
-                bi = i;
-            }
-        }
-        if (bi >= 0 && best > eps2) {
-            keep[bi] = 1;
-            st.push_back({a, bi});
-            st.push_back({bi, b});
-        }
-    }
-}
-
 }  // namespace
 
 extern "C" {
@@ -187,40 +151,132 @@ double gs_arc_length_closed(const int *xy, int n)
     return s;
 }
 
-// cv2.approxPolyDP(curve, epsilon, closed=True): Ramer-Douglas-Peucker.  The closed curve is cut at point 0 and at the
-// point farthest from it; keep[] order follows the input order.  Returns the number of kept points (written to out).
+// cv2.approxPolyDP(curve, epsilon, closed=True).  cv2 is absent from this stack, so this restates the published algorithm of
+// the version the reference pins (opencv-python==4.3.0.38, docker/requirements.txt:5; modules/imgproc/src/approx.cpp,
+// approxPolyDP_<int>) step by step, because its start-point rule and its clean-up pass decide WHICH vertices a polygon in the
+// labelme JSON has (boundary_extractor.py:43-47):
+//   1. three hops "to the point farthest from the current one", starting at point 0: the last hop's two ends are the initial cut;
+//   2. Ramer-Douglas-Peucker on an explicit stack of index ranges that may wrap (left range first, so vertices come out in
+//      contour order starting at the cut), distance test |cross| ^ 2 <= eps^2 * |chord|^2, ties to the first farthest point;
+//   3. a clean-up pass over the result that drops a vertex lying within sqrt(0.5) * eps of the chord of its neighbours when
+//      that chord is neither horizontal nor vertical and the vertex does not fold back.
+// Parity with cv2 proper stays unpinned (no cv2 output exists here); the invariants are tested in tests/test_host_logic.py.
 int gs_approx_poly_closed(const int *xy, int n, double epsilon, int *out)
 {
-    if (n <= 2) {
-        for (int i = 0; i < 2 * n; ++i)
-            out[i] = xy[i];
-        return n;
+    if (n <= 0)
+        return 0;
+    const int count0 = n;
+    int count = n;
+    auto srcx = [&](int i) { return xy[2 * i]; };
+    auto srcy = [&](int i) { return xy[2 * i + 1]; };
+    struct Range { int start, end; };
+    std::vector<Range> stack;
+    std::vector<Pt> dst((size_t)n + 1);
+    int new_count = 0;
+    double eps = epsilon * epsilon;
+    Range slice{0, 0}, right{0, 0};
+    int pos = 0;
+    bool le_eps = false;
+    Pt start_pt{-1000000, -1000000}, end_pt{0, 0}, pt{0, 0};
+    auto read_pt = [&](Pt &p, int &at) {
+        p = Pt{srcx(at), srcy(at)};
+        if (++at >= count) at = 0;
+    };
+    // 1. approximately the two farthest points of the contour
+    right.start = 0;
+    for (int it = 0; it < 3; ++it) {
+        double max_dist = 0;
+        pos = (pos + right.start) % count;
+        read_pt(start_pt, pos);
+        for (int jj = 1; jj < count; ++jj) {
+            read_pt(pt, pos);
+            const double dx = pt.x - start_pt.x, dy = pt.y - start_pt.y;
+            const double dist = dx * dx + dy * dy;
+            if (dist > max_dist) {
+                max_dist = dist;
+                right.start = jj;
+            }
+        }
+        le_eps = max_dist <= eps;
     }
-    std::vector<Pt> pts(n + 1);
-    for (int i = 0; i < n; ++i)
-        pts[i] = {xy[2 * i], xy[2 * i + 1]};
-    pts[n] = pts[0];
-    int far = 0;
-    double best = -1.0;
-    for (int i = 1; i < n; ++i) {
-        const double dx = pts[i].x - pts[0].x, dy = pts[i].y - pts[0].y;
-        if (dx * dx + dy * dy > best) {
-            best = dx * dx + dy * dy;
-            far = i;
+    // 2. the stack
+    if (!le_eps) {
+        right.end = slice.start = pos % count;
+        slice.end = right.start = (right.start + slice.start) % count;
+        stack.push_back(right);
+        stack.push_back(slice);
+    } else {
+        dst[new_count++] = start_pt;
+    }
+    // 3. the recursion, unrolled
+    while (!stack.empty()) {
+        slice = stack.back();
+        stack.pop_back();
+        end_pt = Pt{srcx(slice.end), srcy(slice.end)};
+        pos = slice.start;
+        read_pt(start_pt, pos);
+        if (pos != slice.end) {
+            double max_dist = 0;
+            const double dx = end_pt.x - start_pt.x, dy = end_pt.y - start_pt.y;
+            const bool same = dx == 0 && dy == 0;   // (OpenCV asserts here; a border that passes one pixel twice can get here)
+            while (pos != slice.end) {
+                read_pt(pt, pos);
+                const double dist = same ? std::sqrt((double)(pt.x - start_pt.x) * (pt.x - start_pt.x) + (double)(pt.y - start_pt.y) * (pt.y - start_pt.y))
+                                         : std::fabs((pt.y - start_pt.y) * dx - (pt.x - start_pt.x) * dy);
+                if (dist > max_dist) {
+                    max_dist = dist;
+                    right.start = (pos + count - 1) % count;
+                }
+            }
+            le_eps = same ? max_dist * max_dist <= eps : max_dist * max_dist <= eps * (dx * dx + dy * dy);
+        } else {
+            le_eps = true;
+            start_pt = Pt{srcx(slice.start), srcy(slice.start)};
+        }
+        if (le_eps) {
+            dst[new_count++] = start_pt;
+        } else {
+            right.end = slice.end;
+            slice.end = right.start;
+            stack.push_back(right);
+            stack.push_back(slice);
         }
     }
-    std::vector<char> keep(n + 1, 0);
-    keep[0] = keep[far] = keep[n] = 1;
-    rdp(pts, 0, far, epsilon * epsilon, keep);
-    rdp(pts, far, n, epsilon * epsilon, keep);
-    int m = 0;
-    for (int i = 0; i < n; ++i)
-        if (keep[i]) {
-            out[2 * m] = pts[i].x;
-            out[2 * m + 1] = pts[i].y;
-            ++m;
+    // last stage: remove extra points on the [almost] straight lines
+    count = new_count;
+    auto read_dst = [&](Pt &p, int &at) {
+        p = dst[at];
+        if (++at >= count) at = 0;
+    };
+    if (count > 0) {
+        pos = count - 1;
+        read_dst(start_pt, pos);
+        int wpos = pos;
+        read_dst(pt, pos);
+        for (int i = 0; i < count && new_count > 2; ++i) {
+            read_dst(end_pt, pos);
+            const double dx = end_pt.x - start_pt.x, dy = end_pt.y - start_pt.y;
+            const double dist = std::fabs((pt.x - start_pt.x) * dy - (pt.y - start_pt.y) * dx);
+            const double inner = (double)(pt.x - start_pt.x) * (end_pt.x - pt.x) + (double)(pt.y - start_pt.y) * (end_pt.y - pt.y);
+            if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && inner >= 0) {
+                --new_count;
+                dst[wpos] = start_pt = end_pt;
+                if (++wpos >= count) wpos = 0;
+                read_dst(pt, pos);
+                ++i;
+                continue;
+            }
+            dst[wpos] = start_pt = pt;
+            if (++wpos >= count) wpos = 0;
+            pt = end_pt;
         }
-    return m;
+    }
+    (void)count0;
+    for (int i = 0; i < new_count; ++i) {
+        out[2 * i] = dst[i].x;
+        out[2 * i + 1] = dst[i].y;
+    }
+    return new_count;
 }
 
 }  // extern "C"

@@ -398,13 +398,20 @@ def test_contours_and_polygons():
     poly = contours.approx_poly(c, eps)[:, 0, :]
     assert 8 <= len(poly) < len(c) // 4
     seg_a, seg_b = poly, np.roll(poly, -1, axis=0)
-    for p in c[::7]:                                                  # each original point is within eps of the polygon
+    # known answer worked by hand through OpenCV 4.3's approxPolyDP_ (the algorithm contours.cpp restates): a 10 x 2 rectangle
+    # with mid-points on its long sides, given from a mid-point.  Three farthest-point hops from P0 = (5,0) go to (10,2), to
+    # (0,0), to (10,2): the cut is (0,0) | (10,2), the mid-points have distance 0 from their chords and drop out, the
+    # clean-up pass keeps the four corners -- and the polygon STARTS at the cut (0,0), not at the first input point
+    rect = np.array([[5, 0], [10, 0], [10, 2], [5, 2], [0, 2], [0, 0]], dtype=np.int32)
+    assert contours.approx_poly(rect, 0.5)[:, 0, :].tolist() == [[0, 0], [10, 0], [10, 2], [0, 2]]
+    assert contours.approx_poly(rect, 100.0)[:, 0, :].tolist() == [[0, 0]]             # everything within epsilon: one point (:le_eps)
+    for p in c[::7]:                                                  # each original point is within (1 + sqrt(1/2)) eps of the polygon
         d = []
         for a, b in zip(seg_a, seg_b):
             ab, ap = (b - a).astype(float), (p - a).astype(float)
             t = np.clip(ap @ ab / max(ab @ ab, 1e-12), 0, 1)
             d.append(np.hypot(*(ap - t * ab)))
-        assert min(d) <= eps + 1e-9
+        assert min(d) <= (1.0 + 0.5 ** 0.5) * eps + 1e-9                 # RDP bound + what the clean-up pass may remove
     gy, gx = np.mgrid[0:300, 0:300]
     cm = np.zeros((300, 300), np.uint8)
     cm[(gy - 150) ** 2 + (gx - 150) ** 2 <= 120 ** 2] = 1
