@@ -56,6 +56,8 @@ def parse_args(argv=None):
     ap.add_argument("--host-batches", type=int, default=224,
                     help="batches of the pinned-host pipeline leg (SURVEY 8d: >= 200 after >= 20 warm-up), run as calls of 32 "
                          "batches cycling one set of pinned buffers")
+    ap.add_argument("--host-min-seconds", type=float, default=6.5,
+                    help="the pinned-host leg keeps going for at least this long (continuous GPU work a periodic sampler can see)")
     ap.add_argument("--no-real-crops", action="store_true")
     ap.add_argument("--fail-rank", type=int, default=-1, help="test hook (--dry-run only): this rank exits with code 3 after "
                                                               "the rendezvous, to exercise the parent's fail-fast path")
@@ -339,10 +341,16 @@ def run_rank(args):
         eng.segment_host(host_tiles, mean, std, batch=nb, out_masks=om, out_hist=oh)          # warm-up: 32 batches
         if dist is not None:
             dist.barrier()
+        # at least `calls` calls (>= 200 batches), and at least HOST_LEG_MIN_S of continuous GPU work: a sampler that looks
+        # at the GPU every few seconds (the driver's smi sampler) then sees it busy, and the figure is steadier
+        min_s = 0.0 if args.dry_run else args.host_min_seconds
         t0 = time.perf_counter()
-        for _ in range(calls):
+        done = 0
+        while done < calls or time.perf_counter() - t0 < min_s:
             hm, _ = eng.segment_host(host_tiles, mean, std, batch=nb, out_masks=om, out_hist=oh)
+            done += 1
         el_h = time.perf_counter() - t0
+        calls = done
         n_host = int(host_tiles.shape[0]) * calls
         same = bool((hm[:nb] == mask[0].cpu().numpy()).all())
         tmax_h = max(gather_f64(el_h))

@@ -437,16 +437,31 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
         if (espnet_lanes(models[k]) < 2) nl = 1;
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t npx = (size_t)net_h * net_w;
+    // batches: up to `batch` crops and up to kBatchBytes of crop pixels (one oversize crop still forms a batch of its own), so
+    // that a list of very large crops does not ask for gigabytes of pinned staging per slot
+    constexpr size_t kBatchBytes = 256u << 20;
+    std::vector<int> starts;
     size_t need_in = 0, need_out = 0;
-    for (int first = 0; first < n_crops; first += batch) {
+    int max_cnt = 0;
+    for (int first = 0; first < n_crops;) {
         size_t bi = 0, bo = 0;
-        for (int i = first; i < std::min(first + batch, n_crops); ++i) {
-            bi += al((size_t)heights[i] * widths[i] * 3);
+        int i = first;
+        while (i < n_crops && i - first < batch) {
+            const size_t ci = al((size_t)heights[i] * widths[i] * 3);
+            if (i > first && bi + ci > kBatchBytes)
+                break;
+            bi += ci;
             bo += al((size_t)heights[i] * widths[i]);
+            ++i;
         }
+        starts.push_back(first);
         need_in = std::max(need_in, bi);
         need_out = std::max(need_out, bo);
+        max_cnt = std::max(max_cnt, i - first);
+        first = i;
     }
+    starts.push_back(n_crops);
+    batch = max_cnt;
     constexpr int NSLOT = 4;
     gs_status rc = GS_OK;
     auto fail = [&](hipError_t e, const char *what) {
@@ -511,12 +526,13 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
         s.first = -1;
     };
     int slot = 0, bi = 0;
-    for (int first = 0; first < n_crops && rc == GS_OK; first += batch, slot = (slot + 1) % NSLOT, ++bi) {
+    for (; bi + 1 < (int)starts.size() && rc == GS_OK; slot = (slot + 1) % NSLOT, ++bi) {
+        const int first = starts[bi];
         CropPipe::Slot &s = p.sl[slot];
         hipStream_t compute = p.compute[bi & 1];
         drain(s);   // the slot's previous batch must have left its buffers
         if (rc != GS_OK) break;
-        const int cnt = std::min(batch, n_crops - first);
+        const int cnt = starts[bi + 1] - first;
         s.descs.assign(cnt, gs_crop_desc{});
         size_t oi = 0, oo = 0;
         bool in_direct = true;

@@ -618,6 +618,19 @@ def test_batched_crop_entry_full_size_and_paste(torch_mod, sd1):
     eng.close()
 
 
+def test_batched_crop_entry_splits_large_crops_by_bytes(torch_mod, engine1):
+    """four 4000 x 7000 crops (84 MB each): a batch is capped at 256 MB of crop pixels, so batch=32 runs them as 3 + 1 --
+    same maps and counts as one crop per batch"""
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, noise_tile
+    mean, std = FOLD_MEAN_STD[1]
+    crops = [noise_tile(80 + k, 4000, 7000) for k in range(2)] * 2
+    a = engine1.segment_crops(crops, mean, std, 64, 128, batch=32)
+    b = engine1.segment_crops(crops, mean, std, 64, 128, batch=1)
+    assert all(np.array_equal(x, y) for x, y in zip(a["masks"], b["masks"])) and np.array_equal(a["counts"], b["counts"])
+    assert a["masks"][0].shape == (4000, 7000) and int(a["counts"][0].sum()) == 4000 * 7000
+    assert np.array_equal(a["masks"][0], a["masks"][2])
+
+
 def test_batched_crop_entry_device_resident(torch_mod, engine1):
     """gs_espnet_segment_crops (device-resident, descriptors as kernel arguments) = the host pipeline"""
     torch = torch_mod
