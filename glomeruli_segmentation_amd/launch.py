@@ -142,7 +142,28 @@ def gpu_numa_nodes(sysfs="/sys"):
     return nodes
 
 
-def rank_cpus(local_rank, local_world, allowed=None, sysfs="/sys"):
+def visible_gpu_indices(n_physical, env=None):
+    """physical (KFD-order) index of every visible device, from ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES when they are plain index lists (the first applies to the KFD order, the other two to what it leaves
+    visible); the identity when unset or not numeric (UUIDs)."""
+    env = os.environ if env is None else env
+    vis = list(range(n_physical))
+    for name in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(name)
+        if not v:
+            continue
+        try:
+            idx = [int(t) for t in v.split(",") if t.strip() != ""]
+        except ValueError:
+            continue
+        if all(0 <= i < len(vis) for i in idx):
+            vis = [vis[i] for i in idx]
+        if name != "ROCR_VISIBLE_DEVICES":
+            break          # HIP_ and CUDA_VISIBLE_DEVICES are aliases: the first one set wins
+    return vis
+
+
+def rank_cpus(local_rank, local_world, allowed=None, sysfs="/sys", env=None):
     """The CPUs rank `local_rank` of `local_world` should run on: the allowed CPUs of its GPU's NUMA node, shared evenly with
     the other ranks whose GPUs sit on the same node; an even split of the allowed set when the topology says nothing."""
     if allowed is None:
@@ -153,7 +174,8 @@ def rank_cpus(local_rank, local_world, allowed=None, sysfs="/sys"):
     allowed = sorted(allowed)
     if local_world <= 1 or not allowed:
         return allowed
-    numa = gpu_numa_nodes(sysfs)
+    phys = gpu_numa_nodes(sysfs)
+    numa = [phys[i] for i in visible_gpu_indices(len(phys), env)]      # NUMA node of visible device 0, 1, ...
     if len(numa) >= local_world and numa[local_rank] >= 0:
         node = numa[local_rank]
         cpus = sorted(_parse_cpulist(_read(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist"))) & set(allowed))

@@ -514,13 +514,18 @@ def test_rank_cpu_placement_follows_the_gpu_numa_node(tmp_path):
         d.joinpath("cpulist").write_text(cl + "\n")
     assert launch.gpu_numa_nodes(str(sysfs)) == [0, 0, 1, 1]
     allowed = set(range(32))
-    got = [launch.rank_cpus(r, 4, allowed, str(sysfs)) for r in range(4)]
+    got = [launch.rank_cpus(r, 4, allowed, str(sysfs), {}) for r in range(4)]
     assert got[0] == [0, 1, 2, 3, 4, 5, 6, 7] and got[1] == [16, 17, 18, 19, 20, 21, 22, 23]
     assert got[2] == [8, 9, 10, 11, 12, 13, 14, 15] and got[3] == [24, 25, 26, 27, 28, 29, 30, 31]
     # a cgroup that allows only part of a node; no topology at all -> even split of what is allowed
-    assert launch.rank_cpus(1, 4, set(range(0, 20)), str(sysfs)) == [6, 7, 16, 17, 18, 19]      # node 0 within the cgroup: 0-7,16-19
+    assert launch.rank_cpus(1, 4, set(range(0, 20)), str(sysfs), {}) == [6, 7, 16, 17, 18, 19]      # node 0 within the cgroup: 0-7,16-19
     assert [launch.rank_cpus(r, 2, set(range(6)), str(tmp_path / "none")) for r in range(2)] == [[0, 1, 2], [3, 4, 5]]
     assert launch.rank_cpus(0, 1, {3, 4}, str(sysfs)) == [3, 4]
+    # a visible-device list re-maps local ranks to physical GPUs: ranks 0, 1 on physical GPUs 2, 3 (both on node 1)
+    assert launch.visible_gpu_indices(4, {"HIP_VISIBLE_DEVICES": "2,3"}) == [2, 3]
+    assert launch.visible_gpu_indices(4, {"ROCR_VISIBLE_DEVICES": "1,2,3", "HIP_VISIBLE_DEVICES": "1,2"}) == [2, 3]
+    assert launch.visible_gpu_indices(4, {"HIP_VISIBLE_DEVICES": "GPU-abc"}) == [0, 1, 2, 3]
+    assert launch.rank_cpus(0, 2, allowed, str(sysfs), {"HIP_VISIBLE_DEVICES": "2,3"}) == [8, 9, 10, 11, 12, 13, 14, 15]
 
 
 # ------------------------------------------------------------------------------------------------------------------
