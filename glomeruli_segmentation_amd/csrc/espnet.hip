@@ -86,6 +86,16 @@ static constexpr bool no_vec() { return false; }
 #ifndef CFG_L3_FUSE_P4
 #define CFG_L3_FUSE_P4 0
 #endif
+// The last (unfused) level-3 block in the half-row task shape of the fused ones (CFG_L3_BR_P2R + F_SKIP_PAD) instead of the
+// whole-row four-pixel form: beyond-L2 fetch of that launch 528 -> 235 MB, step 2.853 -> 2.835 ms (profiles/README.md, round 3).
+#ifndef CFG_L3_LAST_P2
+#define CFG_L3_LAST_P2 1
+#endif
+// ... and the level-3 down-sampler's branches likewise: kernel time unchanged (0.1749 -> 0.1748 ms) but its beyond-L2 fetch
+// 371 -> 106 MB, which the other lane's kernels feel: step 2.903 -> 2.878 ms with two batches in flight.
+#ifndef CFG_L3_DOWN_P2
+#define CFG_L3_DOWN_P2 1
+#endif
 // F_A_GLOBAL (weights from L2 through the operand ring, no LDS image): level-3 ESP block 0.167 -> 0.1715 ms, level-2
 // blocks +6-10 %, stride-2 reduces +1-8 %: the 9 us staging phase it removes is cheaper than the slower loop.  Off.
 #ifndef CFG_AGL_L3
@@ -721,6 +731,10 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     L.run(K_L3_DOWN, px3 * (25 * 9 * 128 * 2) + (m->l3_0.fused_next ? px3 * (128 * 25 * 2) : 0), [&] {
         ConvArgs ca = conv_args(m->r3[rd3], wb + m->l3_0.br, m->cc[0], nullptr, n);
         if (m->l3_0.fused_next) {   // no residual here: the four-pixel vector mapping still fits with the second accumulator set
+#if CFG_L3_DOWN_P2
+            if (ca.W % 2 == 0 && !no_vec())
+                return launch_conv_mfma<CFG_L3_BR_P2R, F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3 | F_VEC | SKIP_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+#endif
             if (ca.W % 4 == 0 && !no_vec())
                 return launch_conv_mfma<CFG_L3_BR, F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3 | F_VEC>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
             return launch_conv_mfma<CFG_L3_BR_P2F, F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
@@ -759,6 +773,11 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
                     return launch_conv_mfma<CFG_L3_BR_P2R, F_BNACT | F_RES | F_RES_RING | F_VEC | POL_L3_ESP | AGL_L3 | FUSE_L3 | SKIP_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
                 return launch_conv_mfma<CFG_L3_BR_P2F, F_BNACT | F_RES | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
             }
+#if CFG_L3_LAST_P2
+            // the last (unfused) block in the half-row task shape of the fused ones, tap rows in the halo skipped
+            if (ca.W % 2 == 0 && !no_vec())
+                return launch_conv_mfma<CFG_L3_BR_P2R, F_BNACT | F_RES | F_RES_RING | F_VEC | POL_L3_ESP | AGL_L3 | SKIP_L3>(ca, m->num_cus, s);
+#endif
             // four consecutive pixels per lane and 16-byte accesses when the width allows it (0.170 ms per
             // launch at batch 32), else the two-run mapping with its deeper ring (0.175 ms)
             if (ca.W % 4 == 0 && !no_vec())
