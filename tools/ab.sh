@@ -10,7 +10,7 @@ run() {
 import json,sys
 j=json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
 k=j["kernels_avg_ms"]
-print("%-10s %8.1f patches/s  %.3f ms/step  miou %.6f  agree %.7f  frac %.4f" % (sys.argv[1], j["value"], j["ms_per_step"], j["parity"]["miou_vs_reference"], j["parity"]["pixel_agreement"], j["roofline"]["whole_net_frac"]))
+print("%-10s %8.1f patches/s  %.3f ms/step  (one lane %8.1f)  miou %.6f  agree %.7f  frac %.4f" % (sys.argv[1], j["value"], j["ms_per_step"], j["single_lane"]["value"], j["parity"]["miou_vs_reference"], j["parity"]["pixel_agreement"], j["roofline"]["whole_net_frac"]))
 print("   " + "  ".join("%s=%.4f" % (n.replace("conv_","").replace("_kernel",""), v["avg_ms"]) for n,v in k.items()))
 PY
 }
