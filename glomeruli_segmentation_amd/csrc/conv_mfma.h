@@ -90,6 +90,12 @@ struct ConvArgs {
     long long out3_sn;
     int out3_sc, out3_pitch, out3_off, nout3;
     unsigned out3_img_bytes;
+    // F_BNLOAD (stride-2 reduce): a per-input-channel BN + PReLU is applied to the B operands as they are consumed -- the
+    // consumer side of a "BR over a torch.cat" (Model.py:359) whose producer then stores its RAW output into the concat
+    // buffer and nothing else.  The table [scale | shift | alpha][CINP + KL] follows the weight image in the blob: identity
+    // for channels that arrive normalised, and a last all-zero slot.  k-groups [bnl_s0, bnl_s1) hold the raw channels: BN of
+    // their zero halo would not be zero, so a tap row above the image takes the zero slot and column -1 is re-zeroed.
+    int bnl_s0, bnl_s1;
     int lds_tile_off;   // F_XMERGE: float offset of the per-wave LDS tiles (after the weight image)
     // GS_DIAG builds only:
     int stagger;   // units of 1024 cycles by which waves WAVES/2.. start late (0 = off)
@@ -203,6 +209,7 @@ constexpr int F_S2_FLIP = 1048576;
 // level-3 map: d16 half of the rows, d8 a quarter, ...: 6.5 % of the branch k-steps).  When a chunk is exactly one tap row
 // (G == NSTEP) such a chunk is skipped (wave-uniform), and the operand ring is refilled with the next LIVE chunk instead.
 constexpr int F_SKIP_PAD = 4194304;
+constexpr int F_BNLOAD = 8388608;  // see ConvArgs::bnl_s0
 constexpr int F_X_NOLOAD = 16;  // GS_DIAG timing experiments only (results are garbage): no activation loads in the loop
 constexpr int F_X_NOLDS = 32;   // GS_DIAG: no LDS weight reads in the loop
 constexpr int F_X_NOEPI = 64;   // GS_DIAG: no epilogue at all
@@ -262,6 +269,8 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
     constexpr bool AGL = FLAGS & F_A_GLOBAL, FUSE = FLAGS & F_FUSE1X1;
     constexpr bool S2FLIP = FLAGS & F_S2_FLIP;
     constexpr bool SKIP = FLAGS & F_SKIP_PAD;
+    constexpr bool BNL = FLAGS & F_BNLOAD;
+    static_assert(!BNL || ((FLAGS & F_S2PAIR) && !(FLAGS & (F_BNACT | F_A_GLOBAL | F_VEC))), "F_BNLOAD is for the plain stride-2 reduce");
     static_assert(!SKIP || (TAPS == 9 && STRIDE == 1 && !(FLAGS & (F_S2PAIR | F_XMERGE)) && G * M_KL_OF(MT) == CINP),
                   "F_SKIP_PAD: unit-stride 3x3 with one tap row per chunk");
     static_assert(!S2FLIP || (STRIDE == 2 && TAPS == 9 && NDIL == 1), "F_S2_FLIP is for the stride-2 3x3 reduce");
@@ -311,6 +320,9 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
     const float *bnp = lds + (WFL - LDS_SRC0);   // [scale | shift | alpha][COUT] (x2 with F_DUAL)
     constexpr int BNFL = (BNACT ? 3 * COUT : 0) + (DUAL ? 3 * COUT : 0);
     const float *tab = bnp + BNFL;               // F_FUSE1X1: [NDIL][NACC][64] A operands of the next block's 1x1
+    // F_BNLOAD: [scale | shift | alpha][BNL_C] right after the (rounded) image
+    constexpr int BNL_C = CINP + M::KL;
+    const float *bnl = lds + (conv_image(CINP, TAPS, NDIL, NOUT1, NOUT, BNACT, DUAL, XMERGE_, FUSE ? M::NACC : 0).total - LDS_SRC0);
     const __amdgpu_buffer_rsrc_t rsrc_w =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wpack), 0, AGL ? WFL * 4 : 0, 0x00020000);
 
@@ -519,6 +531,30 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                 aq[g * TXN + tx] = lds[((di * TAPS + tap) * CINP + sidx * KL) * NROW + lbase];
         };
 
+        // F_BNLOAD: the three parameters of this lane's channel in row group g of chunk c (task row yy); one group ahead
+        auto bnl_fetch = [&](int cc, int gg, int yy, bool ff, float &sc2, float &sh2, float &al2) {
+            const int rgc = cc * G + gg;
+            const int ty0c = rgc / NSTEP;
+            const int sidxc = rgc - ty0c * NSTEP;
+            const int tyc = S2FLIP && ff ? TYN - 1 - ty0c : ty0c;
+            const bool padrow = yy * STRIDE + tyc - 1 < 0 && sidxc >= a.bnl_s0 && sidxc < a.bnl_s1;   // (wave-uniform)
+            const int ch = (padrow ? NSTEP : sidxc) * KL + kq;
+            sc2 = bnl[ch];
+            sh2 = bnl[BNL_C + ch];
+            al2 = bnl[2 * BNL_C + ch];
+        };
+        // The transform of row group k+1 is interleaved with the matrix instructions of group k (one value after each MFMA:
+        // three VALU instructions that run while the MFMA occupies the pipe); done in one piece in front of a group's first
+        // MFMA it stalled the wave's matrix stream for ~150 cycles per group (0.156 -> 0.196 ms per launch).
+        float tsc = 1.0f, tsh = 0.0f, tal = 1.0f, tpin = 0.0f;   // parameters of the group being transformed (the next one)
+        float nsc = 1.0f, nsh = 0.0f, nal = 1.0f;                // ... and of the one after it, in flight from LDS
+        auto bnl_apply = [&](float &v, float sc2, float sh2, float al2, float pin2, bool zero) {
+            v = v * sc2 + sh2;
+            v = prelu_med3(v, al2, pin2);
+            if (zero)
+                v = 0.0f;
+        };
+
         // prologue: the first chunk's activations are requested before the weights are staged, so
         // their latency overlaps the LDS fill
         if (task == t0) {
@@ -572,6 +608,16 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                     fetch_a(c_first, g, tx, flip);
         }
 
+        if (BNL) {   // the task's first row group is transformed here, in one piece (once per ~150 k cycles)
+            bnl_fetch(c_first, 0, y, flip, tsc, tsh, tal);
+            bnl_fetch(c_first, 1, y, flip, nsc, nsh, nal);
+            tpin = prelu_pin(tal);
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    bnl_apply(bl[0][p][t], tsc, tsh, tal, tpin, t == 0 && p == 0 && x0 == 0 && px == 0);
+        }
         prefetch_res(0);
         if (FUSE) {
 #pragma unroll
@@ -619,6 +665,18 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
 #pragma unroll
                 for (int tx = 0; tx < TXN; ++tx) {
                     const int u = g * TXN + tx;
+                    // F_BNLOAD: while group g multiplies, group g+1 (of this chunk, or the first of the next) is transformed
+                    const bool ahead = BNL && (g + 1 < G || !last);
+                    if (BNL && tx == 0) {
+                        tsc = nsc;
+                        tsh = nsh;
+                        tal = nal;
+                        tpin = prelu_pin(tal);
+                        if (g + 2 < G)
+                            bnl_fetch(c, g + 2, y, flip, nsc, nsh, nal);
+                        else if (!last)
+                            bnl_fetch(nx, g + 2 - G, y, flip, nsc, nsh, nal);
+                    }
 #if defined(GS_DIAG) && defined(CFG_X_MFMA_KEEP)
                     // ceiling experiment (results are garbage): only every CFG_X_MFMA_KEEP-th k-step's matrix instructions
                     // are issued; the operands of the others are still loaded and waited for
@@ -631,8 +689,15 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                     } else
 #endif
 #pragma unroll
-                    for (int p = 0; p < P; ++p)
+                    for (int p = 0; p < P; ++p) {
                         acc[p] = M::run(aq[u], S2P ? bl[S2P ? g : 0][p][S2P ? tx : 0] : bq[S2P ? 0 : u][p], acc[p]);
+                        if (ahead) {   // element e = tx*P + p of the next group: (pixel e / 3, tap e % 3)
+                            constexpr int GN = 0;
+                            const int e = tx * P + p;
+                            if (e < 3 * P)
+                                bnl_apply(bl[S2P ? (g + 1) % G : GN][e / 3][e % 3], tsc, tsh, tal, tpin, e == 0 && x0 == 0 && px == 0);
+                        }
+                    }
                     if (!S2P)
                         fetch_b(rs, sb, nx, g, tx, fl);
                     else if (tx == 2)
@@ -822,8 +887,9 @@ gs_status launch_conv_mfma(ConvArgs a, int num_cus, hipStream_t stream)
     if (const char *e = std::getenv("GS_STAGGER"))
         a.stagger = std::atoi(e);
 #endif
-    a.wfloats = im.total;
-    const int lds_floats = im.total - ((FLAGS & F_A_GLOBAL) ? im.w : 0);
+    constexpr int EXTRA = (FLAGS & F_BNLOAD) ? 3 * (CINP + Mfma<MT>::KL) : 0;   // the on-load BN / PReLU table follows the image
+    a.wfloats = im.total + EXTRA;
+    const int lds_floats = im.total + EXTRA - ((FLAGS & F_A_GLOBAL) ? im.w : 0);
     a.lds_tile_off = (lds_floats + 255) / 256 * 256;
     const size_t lds_bytes = (size_t)(a.lds_tile_off + ((FLAGS & F_XMERGE) ? WAVES * MT * (P * MT + 4) : 0)) * sizeof(float);   // whole 1-KiB DMA pieces (+ tiles)
     static std::mutex mu;

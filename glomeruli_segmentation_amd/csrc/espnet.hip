@@ -46,6 +46,10 @@ void set_error(const char *fmt, ...)
 #endif
 #define CFG_L2_BR_P4     16, 8,   12,  9,   1,     5,   16,   12,   L2SP, L2SG   // shipped (4, 9): a whole dilation's operands in flight
 #define CFG_L3_C1S       32, 8,   132, 9,   2,     1,   25,   25,   4, 6
+#ifndef L3C1S_BNL_G
+#define L3C1S_BNL_G 6     // F_BNLOAD form; a deeper ring measured no better (9: 0.192 ms vs 0.189) or spilled (11: 0.287)
+#endif
+#define CFG_L3_C1S_BNL   32, 8,   132, 9,   2,     1,   25,   25,   4, L3C1S_BNL_G
 #define CFG_L3_C1        32, 8,   128, 1,   1,     1,   25,   25,   4, 16
 #define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 3
 #define CFG_L3_BR_P2     32, 8,   26,  9,   1,     5,   28,   25,   2, 13
@@ -122,6 +126,17 @@ constexpr int S2FLIP_L2 = (CFG_S2_FLIP & 1) ? F_S2_FLIP : 0, S2FLIP_L3 = (CFG_S2
 #define CFG_SKIP_PAD 1
 #endif
 constexpr int SKIP_L3 = CFG_SKIP_PAD ? F_SKIP_PAD : 0;
+// Lazy b2: b2 = BR(131) over cat([output1, output1_0, inp2]) (Model.py:359) used to be fused into its producers, the
+// down-sampler writing output1_0 TWICE (raw for the level-2 ESP blocks, b2-normalised into planes 64..127 of output1_cat).
+// The normalised copy is now never written: its two consumers -- the level-3 stride-2 reduce (F_IN2: BN + PReLU on the B
+// operands of those 64 channels) and dec2 -- read the raw output and apply b2 on load.  The store it saves is 268 MB per
+// 32-tile step; dropping it outright (a timing-only build) moved the down-sampler 0.231 -> 0.186 ms and the two-lane step
+// 2.896 -> 2.771 ms.  Built: down-sampler 0.228 -> 0.183 ms, the stride-2 reduce 0.156 -> 0.190 ms (its on-load BN + PReLU is
+// interleaved with the matrix instructions but not free: that kernel's matrix pipe is 81 % busy), dec2 unchanged; one lane
+// about even, two batches in flight 2.87 -> 2.81-2.82 ms per step (profiles/README.md, round 3).
+#ifndef CFG_LAZY_B2
+#define CFG_LAZY_B2 1
+#endif
 
 // Every unit-stride conv launch exists in two pixel mappings; the vector one (F_VEC) needs the output width to be a
 // multiple of P (the 9th configuration parameter).
@@ -208,6 +223,7 @@ struct Model {
     size_t prob_bytes = 0;
     std::map<std::string, std::pair<Act, int>> stages;   // name -> (activation, channels) of the last forward
     int last_n = 0;
+    bool b2_lazy = false;    // planes 64..127 of the stage "b2" are not materialised by the last forward (read_stage fills them)
 
     // host pipeline (gs_espnet_segment_host): two slots of pinned + device staging, kept across calls
     struct Slot {
@@ -304,7 +320,8 @@ static void pack_conv(const float *w, int cout, int cin, int k, float *dst, int 
 // `next` names the block whose c1 (1x1 reduce of THIS block's output, Model.py:193) is computed in this block's epilogue
 // (F_FUSE1X1); empty = no fusion.
 static bool pack_block(WeightTable &t, BlobBuilder &bb, const std::string &pre, bool down, int level, PackedConv &pc,
-                       const float *dual = nullptr, int dual_coff = 0, int dual_c = 0, const std::string &next = "")
+                       const float *dual = nullptr, int dual_coff = 0, int dual_c = 0, const std::string &next = "",
+                       const float *in2_bn = nullptr, int in2_c0 = 0, int in2_cn = 0, int in2_c = 0)
 {
     // level 2: cin 19 (down) / 64, n = 12, n1 = 16;  level 3: cin 131 (down) / 128, n = 25, n1 = 28
     const int n = level == 2 ? 12 : 25, n1 = level == 2 ? 16 : 28, nOut = n1 + 4 * n;
@@ -315,8 +332,19 @@ static bool pack_block(WeightTable &t, BlobBuilder &bb, const std::string &pre, 
     const float *wc1 = t.get(pre + ".c1.conv.weight", {n, cin, down ? 3 : 1, down ? 3 : 1});
     if (!t.ok)
         return false;
-    pc.c1 = bb.reserve(conv_wfloats(cinp, taps, 1, n, n, false));
+    const int c1_floats = conv_wfloats(cinp, taps, 1, n, n, false);
+    const int bnl_c = cinp + kl;   // F_BNLOAD table: one entry per (padded) input channel + an all-zero slot of one k-group
+    pc.c1 = bb.reserve(c1_floats + (in2_bn ? 3 * bnl_c : 0));
     pack_conv(wc1, n, cin, down ? 3 : 1, bb.data.data() + pc.c1, 0, taps, cinp, n);
+    if (in2_bn) {   // [scale | shift | alpha][bnl_c]: identity, except the cat's BR for the channels that are stored raw
+        float *x = bb.data.data() + pc.c1 + c1_floats;
+        for (int c = 0; c < bnl_c; ++c) {
+            const bool raw = c >= in2_c0 && c < in2_c0 + in2_cn, zero = c >= cinp;
+            x[c] = zero ? 0.0f : raw ? in2_bn[c] : 1.0f;
+            x[bnl_c + c] = zero ? 0.0f : raw ? in2_bn[in2_c + c] : 0.0f;
+            x[2 * bnl_c + c] = raw ? in2_bn[2 * in2_c + c] : 1.0f;
+        }
+    }
 
     const int rcinp = (n + kl - 1) / kl * kl;
     const int mt = level == 2 ? 16 : 32, nacc = level == 2 ? 4 : 16;
@@ -405,6 +433,11 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
     m->o2c = make_act(cls, cls, H2, W2, 0, 0, 0, 0);
     m->tt = make_act(2 * cls, 2 * cls, H2, W2, 0, 0, 0, 0);
     m->ff = make_act(cls, cls, H1, W1, 0, 0, 0, 0);
+    // Lazy b2 (p > 0): output1_0 is stored RAW, once, straight into planes 64..127 of output1_cat -- bb[0] becomes a view of
+    // them -- and the consumers of output1_cat apply b2 to those planes on load (CFG_LAZY_B2 above).
+    const bool lazy_b2 = m->p > 0 && CFG_LAZY_B2;
+    if (lazy_b2)
+        m->bb[0] = Act();   // no storage of its own
     Act *all[] = {&m->a0c, &m->inp1, &m->inp2, &m->r2[0], &m->r2[1], &m->bb[0], &m->bb[1], &m->bb[2], &m->a1, &m->r3[0], &m->r3[1],
                   &m->cc[0], &m->cc[1], &m->cc[2], &m->o2c, &m->tt, &m->ff};
     for (Act *a : all) {   // kernels address one image with 32-bit byte offsets (buffer soffset / voffset)
@@ -430,6 +463,12 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
     for (Act *a : all) {
         a->base = reinterpret_cast<float *>(static_cast<char *>(ws) + at);
         at += round_up(a->bytes(n) + slack, 256);
+    }
+    if (lazy_b2) {
+        m->bb[0] = m->a1;
+        m->bb[0].base = m->a1.base + (long long)64 * m->a1.sc;
+        m->bb[0].C = 64;
+        m->bb[0].Cp = 64;
     }
     m->ee = m->a0c;   // comb_l2_l3 = the first planes of the concat buffer
     m->ee.C = cls;
@@ -661,13 +700,24 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         return a;
     };
     const bool fuse_b2 = m->p > 0;
+    const bool lazy_b2 = fuse_b2 && CFG_LAZY_B2;
+    m->b2_lazy = lazy_b2;
     int rd2 = 0;   // index of the reduced map the next level-2 branch kernel reads
     L.run(K_L2_DOWN, px2 * (12 * 9 * 64 * 2) + (m->l2_0.fused_next ? px2 * (64 * 12 * 2) : 0), [&] {
         ConvArgs ca = conv_args(m->r2[rd2], wb + m->l2_0.br, m->bb[0], nullptr, n);
+        if (lazy_b2) {   // raw output only: b2 is applied by the consumers (level-3 stride-2 reduce, dec2)
+            if (m->l2_0.fused_next)
+                return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
+            return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
+        }
         if (fuse_b2) {
             ca = with_dual(ca, 64);
 #ifdef GS_DIAG
             if (m->variant == 150) return launch_vec<F_BNACT | F_DUAL, CFG_L2_BR>(ca, m->num_cus, s);
+            // 151 (timing only, results wrong): the b2-normalised second store of the down-sampler dropped -- the ceiling of
+            // "let the consumers apply b2 on load" (profiles/README.md, round 3)
+            if (m->variant == 151 && m->l2_0.fused_next)
+                return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2, CFG_L2_BR_P4>(with_fused(conv_args(m->r2[rd2], wb + m->l2_0.br, m->bb[0], nullptr, n), m->r2[rd2 ^ 1], 12), m->num_cus, s);
 #endif
             if (m->l2_0.fused_next)
                 return launch_vec<F_BNACT | F_DUAL | POL_L2_DOWN | AGL_L2 | FUSE_L2, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
@@ -726,6 +776,12 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         if (m->variant == 41)
             return launch_conv_mfma<CFG_L3_C1S, 0>(conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n), m->num_cus, s);
 #endif
+        if (lazy_b2) {   // planes 64..127 of output1_cat hold output1_0 RAW: b2 is applied to the B operands on load
+            ConvArgs ca = conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n);
+            ca.bnl_s0 = 64 / 2;      // k-groups of two channels
+            ca.bnl_s1 = 128 / 2;
+            return launch_conv_mfma<CFG_L3_C1S_BNL, F_S2PAIR | POL_L3_C1S | S2FLIP_L3 | F_BNLOAD>(ca, m->num_cus, s);
+        }
         return launch_conv_mfma<CFG_L3_C1S, F_S2PAIR | POL_L3_C1S | AGL_S2 | S2FLIP_L3>(conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n), m->num_cus, s);
     });
     L.run(K_L3_DOWN, px3 * (25 * 9 * 128 * 2) + (m->l3_0.fused_next ? px3 * (128 * 25 * 2) : 0), [&] {
@@ -742,6 +798,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         return launch_vec<F_BNACT | POL_L3_DOWN | AGL_L3, CFG_L3_BR>(ca, m->num_cus, s);
     });
     bool have_r3 = m->l3_0.fused_next;
+    set_stage("level3_reduce", m->r3[rd3], 25);      // (debug: valid until the second ESP block overwrites the map)
     rd3 ^= have_r3 ? 1 : 0;
     set_stage("level3_0", m->cc[0], 128);
     int cur3 = 0;
@@ -812,6 +869,10 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     L.run(K_DEC2, px2 * (131 * CLS * 2), [&] {
         Dec2Args a{};
         a.a1 = view(m->a1);
+        a.raw = view(m->bb[0]);
+        a.b2 = wb + m->b2;
+        a.raw_c0 = 64;
+        a.raw_cn = lazy_b2 ? 64 : 0;
         a.o2c = view(m->o2c);
         a.w3c = wb + m->w3c;
         a.br = wb + m->cbr0;
@@ -1045,12 +1106,13 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
     m.b2 = bb.push(b2f.data(), 393);
     auto next2 = [&](int i) { return (CFG_FUSE_L2 && i < p) ? e + "level2." + std::to_string(i) : std::string(); };
     auto next3 = [&](int i) { return ((CFG_FUSE_L3 == 2 || (CFG_FUSE_L3 == 1 && i == 0)) && i < q) ? e + "level3." + std::to_string(i) : std::string(); };
-    if (!pack_block(t, bb, e + "level2_0", true, 2, m.l2_0, p > 0 ? b2f.data() : nullptr, 64, 131, next2(0))) return GS_ERR_INVALID;
+    // (lazy b2: the down-sampler has no second store, so its image carries no second BN section)
+    if (!pack_block(t, bb, e + "level2_0", true, 2, m.l2_0, (p > 0 && !CFG_LAZY_B2) ? b2f.data() : nullptr, 64, 131, next2(0))) return GS_ERR_INVALID;
     m.l2.resize(p);
     for (int i = 0; i < p; ++i)
         if (!pack_block(t, bb, e + "level2." + std::to_string(i), false, 2, m.l2[i], i == p - 1 ? b2f.data() : nullptr, 0, 131, next2(i + 1)))
             return GS_ERR_INVALID;
-    if (!pack_block(t, bb, e + "level3_0", true, 3, m.l3_0, nullptr, 0, 0, next3(0))) return GS_ERR_INVALID;
+    if (!pack_block(t, bb, e + "level3_0", true, 3, m.l3_0, nullptr, 0, 0, next3(0), b2f.data(), 64, 64, 131)) return GS_ERR_INVALID;
     m.l3.resize(q);
     for (int i = 0; i < q; ++i)
         if (!pack_block(t, bb, e + "level3." + std::to_string(i), false, 3, m.l3[i], nullptr, 0, 0, next3(i + 1))) return GS_ERR_INVALID;
@@ -1270,6 +1332,8 @@ gs_status gs_espnet_read_stage(gs_espnet *h, const char *stage, int image, float
     float *tmp = nullptr;
     GS_HIP(hipMalloc(reinterpret_cast<void **>(&tmp), count * sizeof(float)));
     hipLaunchKernelGGL(unpad_kernel, dim3(blocks_for((long long)count)), dim3(256), 0, 0, view(a), image, C, tmp);
+    if (m.b2_lazy && std::string(stage) == "b2")   // planes 64..127 are kept raw in the workspace: normalise the copy
+        hipLaunchKernelGGL(b2_apply_kernel, dim3(blocks_for((long long)64 * a.H * a.W)), dim3(256), 0, 0, tmp, m.dblob + m.b2, a.H * a.W, 64, 64);
     hipError_t e = hipMemcpy(dst, tmp, count * sizeof(float), hipMemcpyDeviceToHost);
     hipFree(tmp);
     GS_HIP(e);

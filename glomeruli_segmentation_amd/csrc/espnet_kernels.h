@@ -421,6 +421,9 @@ __global__ void __launch_bounds__(256) dec1_kernel(const Dec1Args a)
 // reference: Model.py:372-373 (level3_C = C(131,classes,1); combine_l2_l3[0] = BR(2*classes))
 struct Dec2Args {
     ActV a1;             // output1_cat (131 channels)
+    ActV raw;            // lazy b2: planes raw_c0 .. raw_c0 + raw_cn - 1 of output1_cat are not materialised; they are
+    const float *b2;     // BN + PReLU (b2 folded [3][131]) of this raw block output, applied here on load
+    int raw_c0, raw_cn;
     ActV o2c;            // output2_c (CLS)
     const float *w3c;    // level3_C.conv.weight packed [131][8] (first CLS of each row used)
     const float *br;     // combine_l2_l3.0 folded [3][2*CLS]
@@ -442,10 +445,28 @@ __global__ void __launch_bounds__(256) dec2_kernel(const Dec2Args a)
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = 0.0f;
+    // (three plain loops, so that each keeps its loads batched: a range test inside one loop cost 0.045 ms)
+    const int r0 = a.raw_cn > 0 ? a.raw_c0 : 131, r1 = a.raw_cn > 0 ? a.raw_c0 + a.raw_cn : 131;
 #pragma unroll 8
-    for (int c = 0; c < 131; ++c) {
+    for (int c = 0; c < r0; ++c) {
         const float v = ld_stream<NT_DEC2_LD>(at(a.a1, n, c, y, x));
         const float *pc = a.w3c + c * 8;   // level3_C weights packed [c][8]: one scalar load per channel
+#pragma unroll
+        for (int k = 0; k < CLS; ++k)
+            s[k] = fmaf(pc[k], v, s[k]);
+    }
+#pragma unroll 8
+    for (int c = r0; c < r1; ++c) {      // lazy b2: these planes are raw; BN + PReLU of the cat's BR here
+        const float v = bn_prelu(ld_stream<NT_DEC2_LD>(at(a.raw, n, c - r0, y, x)), a.b2, 131, c);
+        const float *pc = a.w3c + c * 8;
+#pragma unroll
+        for (int k = 0; k < CLS; ++k)
+            s[k] = fmaf(pc[k], v, s[k]);
+    }
+#pragma unroll 8
+    for (int c = r1; c < 131; ++c) {
+        const float v = ld_stream<NT_DEC2_LD>(at(a.a1, n, c, y, x));
+        const float *pc = a.w3c + c * 8;
 #pragma unroll
         for (int k = 0; k < CLS; ++k)
             s[k] = fmaf(pc[k], v, s[k]);
@@ -621,6 +642,17 @@ __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
         if (threadIdx.x < CLS && lhist[threadIdx.x])
             atomicAdd(&a.hist[(long long)n * CLS + threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
     }
+}
+
+// lazy b2 (debug / tests): planes c0 .. c0+cn-1 of a dense CHW copy of output1_cat are raw block outputs; apply b2 to them
+__global__ void __launch_bounds__(256) b2_apply_kernel(float *chw, const float *b2, int hw, int c0, int cn)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)cn * hw)
+        return;
+    const int c = c0 + (int)(idx / hw);
+    float *p = chw + (long long)c0 * hw + idx;
+    *p = bn_prelu(*p, b2, 131, c);
 }
 
 // copy one image of a padded activation to a dense CHW buffer (debug / tests)
