@@ -674,10 +674,10 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
 #endif
         return launch_conv_mfma<CFG_L2_C1S, F_S2PAIR | POL_L2_C1S | AGL_S2 | S2FLIP_L2>(conv_args(m->a0, wb + m->l2_0.c1, m->r2[0], nullptr, n), m->num_cus, s);
     });
-    // b2 = BR(131) over cat([output1, output1_0, inp2]) (Model.py:359) is fused into its producers:
-    // the down-sampler stores output1_0 twice (raw for the ESP blocks, b2-normalised into planes
-    // 64..127 of output1_cat), the last ESP block stores only its b2-normalised form (planes 0..63)
-    // and the pool kernel writes planes 128..130.  With p == 0 the unfused cat kernel runs instead.
+    // b2 = BR(131) over cat([output1, output1_0, inp2]) (Model.py:359) never runs as a kernel: the last ESP block stores
+    // only its b2-normalised form (planes 0..63 of output1_cat), the pool kernel writes planes 128..130 normalised, and
+    // output1_0 is stored RAW into planes 64..127 (lazy b2, CFG_LAZY_B2 above: the consumers normalise on load; the eager
+    // form stored it twice, raw for the ESP blocks and normalised for the cat).  With p == 0 the unfused cat kernel runs.
     auto with_dual = [&](ConvArgs a, int coff) {
         a.out2 = m->a1.base;
         a.out2_sn = m->a1.sn;
