@@ -250,6 +250,11 @@ constexpr ConvImage conv_image(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT
 #ifndef CFG_RES_RING_DIV
 #define CFG_RES_RING_DIV 2
 #endif
+// F_BNLOAD: skip the (exact) identity transform of row groups that hold no raw channel, at the price of a wave-uniform
+// branch after every matrix instruction of the group before
+#ifndef CFG_BNL_SKIP_ID
+#define CFG_BNL_SKIP_ID 0
+#endif
 #ifndef CFG_STAGE_ROT
 #define CFG_STAGE_ROT 17   // 0 = every workgroup stages the weight image in the same order
 #endif
@@ -532,12 +537,13 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         };
 
         // F_BNLOAD: the three parameters of this lane's channel in row group g of chunk c (task row yy); one group ahead
-        auto bnl_fetch = [&](int cc, int gg, int yy, bool ff, float &sc2, float &sh2, float &al2) {
+        auto bnl_fetch = [&](int cc, int gg, int yy, bool ff, float &sc2, float &sh2, float &al2, bool &raw) {
             const int rgc = cc * G + gg;
             const int ty0c = rgc / NSTEP;
             const int sidxc = rgc - ty0c * NSTEP;
             const int tyc = S2FLIP && ff ? TYN - 1 - ty0c : ty0c;
-            const bool padrow = yy * STRIDE + tyc - 1 < 0 && sidxc >= a.bnl_s0 && sidxc < a.bnl_s1;   // (wave-uniform)
+            raw = sidxc >= a.bnl_s0 && sidxc < a.bnl_s1;                // (wave-uniform) the other groups have identity parameters
+            const bool padrow = yy * STRIDE + tyc - 1 < 0 && raw;
             const int ch = (padrow ? NSTEP : sidxc) * KL + kq;
             sc2 = bnl[ch];
             sh2 = bnl[BNL_C + ch];
@@ -548,6 +554,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         // MFMA it stalled the wave's matrix stream for ~150 cycles per group (0.156 -> 0.196 ms per launch).
         float tsc = 1.0f, tsh = 0.0f, tal = 1.0f, tpin = 0.0f;   // parameters of the group being transformed (the next one)
         float nsc = 1.0f, nsh = 0.0f, nal = 1.0f;                // ... and of the one after it, in flight from LDS
+        bool traw = false, nraw = false;                         // whether those groups hold raw channels at all (CFG_BNL_SKIP_ID)
         auto bnl_apply = [&](float &v, float sc2, float sh2, float al2, float pin2, bool zero) {
             v = v * sc2 + sh2;
             v = prelu_med3(v, al2, pin2);
@@ -609,8 +616,8 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         }
 
         if (BNL) {   // the task's first row group is transformed here, in one piece (once per ~150 k cycles)
-            bnl_fetch(c_first, 0, y, flip, tsc, tsh, tal);
-            bnl_fetch(c_first, 1, y, flip, nsc, nsh, nal);
+            bnl_fetch(c_first, 0, y, flip, tsc, tsh, tal, traw);
+            bnl_fetch(c_first, 1, y, flip, nsc, nsh, nal, nraw);
             tpin = prelu_pin(tal);
 #pragma unroll
             for (int p = 0; p < P; ++p)
@@ -671,11 +678,12 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                         tsc = nsc;
                         tsh = nsh;
                         tal = nal;
+                        traw = nraw;
                         tpin = prelu_pin(tal);
                         if (g + 2 < G)
-                            bnl_fetch(c, g + 2, y, flip, nsc, nsh, nal);
+                            bnl_fetch(c, g + 2, y, flip, nsc, nsh, nal, nraw);
                         else if (!last)
-                            bnl_fetch(nx, g + 2 - G, y, flip, nsc, nsh, nal);
+                            bnl_fetch(nx, g + 2 - G, y, flip, nsc, nsh, nal, nraw);
                     }
 #if defined(GS_DIAG) && defined(CFG_X_MFMA_KEEP)
                     // ceiling experiment (results are garbage): only every CFG_X_MFMA_KEEP-th k-step's matrix instructions
@@ -691,7 +699,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
                         acc[p] = M::run(aq[u], S2P ? bl[S2P ? g : 0][p][S2P ? tx : 0] : bq[S2P ? 0 : u][p], acc[p]);
-                        if (ahead) {   // element e = tx*P + p of the next group: (pixel e / 3, tap e % 3)
+                        if (ahead && (!CFG_BNL_SKIP_ID || traw)) {   // element e = tx*P + p of the next group: (pixel e / 3, tap e % 3)
                             constexpr int GN = 0;
                             const int e = tx * P + p;
                             if (e < 3 * P)
