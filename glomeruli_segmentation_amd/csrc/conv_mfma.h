@@ -556,6 +556,19 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         float nsc = 1.0f, nsh = 0.0f, nal = 1.0f;                // ... and of the one after it, in flight from LDS
         bool traw = false, nraw = false;                         // whether those groups hold raw channels at all (CFG_BNL_SKIP_ID)
         auto bnl_apply = [&](float &v, float sc2, float sh2, float al2, float pin2, bool zero) {
+#if defined(GS_DIAG) && defined(CFG_BNL_ABLATE)
+            // timing-only ablations (results wrong): 1 = only wait for the operand (no arithmetic), 2 = the arithmetic on a
+            // value that does not come from the operand (no early wait)
+            if (CFG_BNL_ABLATE == 1) {
+                asm volatile("" : "+v"(v));
+                return;
+            }
+            float w = sc2;
+            w = w * sc2 + sh2;
+            w = prelu_med3(w, al2, pin2);
+            asm volatile("" ::"v"(w));
+            return;
+#endif
             v = v * sc2 + sh2;
             v = prelu_med3(v, al2, pin2);
             if (zero)
