@@ -250,11 +250,6 @@ constexpr ConvImage conv_image(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT
 #ifndef CFG_RES_RING_DIV
 #define CFG_RES_RING_DIV 2
 #endif
-// F_BNLOAD: skip the (exact) identity transform of row groups that hold no raw channel, at the price of a wave-uniform
-// branch after every matrix instruction of the group before
-#ifndef CFG_BNL_SKIP_ID
-#define CFG_BNL_SKIP_ID 0
-#endif
 #ifndef CFG_STAGE_ROT
 #define CFG_STAGE_ROT 17   // 0 = every workgroup stages the weight image in the same order
 #endif
@@ -554,25 +549,31 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         // MFMA it stalled the wave's matrix stream for ~150 cycles per group (0.156 -> 0.196 ms per launch).
         float tsc = 1.0f, tsh = 0.0f, tal = 1.0f, tpin = 0.0f;   // parameters of the group being transformed (the next one)
         float nsc = 1.0f, nsh = 0.0f, nal = 1.0f;                // ... and of the one after it, in flight from LDS
-        bool traw = false, nraw = false;                         // whether those groups hold raw channels at all (CFG_BNL_SKIP_ID)
-        auto bnl_apply = [&](float &v, float sc2, float sh2, float al2, float pin2, bool zero) {
+        bool traw = false, nraw = false;                         // (whether those groups hold raw channels at all; an identity-skipping
+                                                                 // variant behind a per-MFMA uniform branch measured slower)
+        // (the transformed operands go to a two-group buffer of their own: rewritten in place, every value cost a register copy --
+        // 72 v_mov per chunk -- because the ring's registers are load destinations)
+        float bt[BNL ? 2 : 1][P][3];
+        static_assert(!BNL || G % 2 == 0, "F_BNLOAD: the two-group operand buffer alternates by row-group parity");
+        auto bnl_apply = [&](float &dst, float v, float sc2, float sh2, float al2, float pin2, bool zero) {
 #if defined(GS_DIAG) && defined(CFG_BNL_ABLATE)
             // timing-only ablations (results wrong): 1 = only wait for the operand (no arithmetic), 2 = the arithmetic on a
             // value that does not come from the operand (no early wait)
             if (CFG_BNL_ABLATE == 1) {
                 asm volatile("" : "+v"(v));
+                dst = v;
                 return;
             }
             float w = sc2;
             w = w * sc2 + sh2;
             w = prelu_med3(w, al2, pin2);
             asm volatile("" ::"v"(w));
+            dst = v;
             return;
 #endif
             v = v * sc2 + sh2;
             v = prelu_med3(v, al2, pin2);
-            if (zero)
-                v = 0.0f;
+            dst = zero ? 0.0f : v;
         };
 
         // prologue: the first chunk's activations are requested before the weights are staged, so
@@ -636,7 +637,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             for (int p = 0; p < P; ++p)
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
-                    bnl_apply(bl[0][p][t], tsc, tsh, tal, tpin, t == 0 && p == 0 && x0 == 0 && px == 0);
+                    bnl_apply(bt[0][p][t], bl[0][p][t], tsc, tsh, tal, tpin, t == 0 && p == 0 && x0 == 0 && px == 0);
         }
         prefetch_res(0);
         if (FUSE) {
@@ -711,12 +712,13 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
 #endif
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
-                        acc[p] = M::run(aq[u], S2P ? bl[S2P ? g : 0][p][S2P ? tx : 0] : bq[S2P ? 0 : u][p], acc[p]);
-                        if (ahead && (!CFG_BNL_SKIP_ID || traw)) {   // element e = tx*P + p of the next group: (pixel e / 3, tap e % 3)
-                            constexpr int GN = 0;
+                        acc[p] = M::run(aq[u], BNL ? bt[BNL ? g & 1 : 0][p][S2P ? tx : 0]
+                                                   : S2P ? bl[S2P ? g : 0][p][S2P ? tx : 0] : bq[S2P ? 0 : u][p], acc[p]);
+                        if (ahead) {   // element e = tx*P + p of the next group: (pixel e / 3, tap e % 3)
                             const int e = tx * P + p;
                             if (e < 3 * P)
-                                bnl_apply(bl[S2P ? (g + 1) % G : GN][e / 3][e % 3], tsc, tsh, tal, tpin, e == 0 && x0 == 0 && px == 0);
+                                bnl_apply(bt[BNL ? (g + 1) & 1 : 0][e / 3][e % 3], bl[S2P ? (g + 1) % G : 0][e / 3][e % 3], tsc, tsh, tal, tpin,
+                                          e == 0 && x0 == 0 && px == 0);
                         }
                     }
                     if (!S2P)
