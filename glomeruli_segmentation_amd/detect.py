@@ -268,7 +268,7 @@ def split_all(args, detector, rank=0, world=1, dist=None, out=sys.stdout):
                 out_file.flush()
                 log_file.write('"{}",{}\n'.format(meta["file_name"], time.time() - t0))
                 log_file.flush()
-                print('{}: {} windows scanned, {} boxes'.format(entry, "all", len(rows)), file=out)
+                print('{}: {} boxes at or above the threshold'.format(entry, len(rows)), file=out)
     finally:
         if out_file:
             out_file.close()
