@@ -96,3 +96,17 @@ def test_torch_port_matches_golden(sd1):
     for tag in "ac":
         out = port.espnet_forward(port.preprocess(z["tile_" + tag][None], mean, std), sd)[0].numpy()
         assert np.abs(out - z["logits_" + tag]).max() <= TOL
+
+
+@pytest.mark.parametrize("p,q", [(2, 3), (1, 2), (3, 1), (1, 1)])
+def test_other_depths_against_the_reference(p, q):
+    """ESPNet(5, p, q) of the REFERENCE with seeded random weights (tests/golden/make_golden_depths.py): the oracle's graph
+    composition for depths other than the shipped (2, 8)"""
+    from conftest import load_golden, random_state_dict
+    from oracle import espnet_oracle as orc
+    z = load_golden("depths.npz")
+    sd = random_state_dict(p, q, seed=10 * p + q)
+    lg, mask, hist = orc.segment_tile(z["tile"], sd, [float(v) for v in z["mean"]], [float(v) for v in z["std"]], p, q)
+    ref = z["logits_p%d_q%d" % (p, q)]
+    assert lg.shape == ref.shape
+    assert np.abs(lg - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))
