@@ -215,6 +215,24 @@ def test_weight_fixture_digest(sd1):
         assert h.hexdigest() == want, fold
 
 
+def test_metrics_relabel_and_palette_match_reference_golden():
+    """segment.confusion / metric_right against the reference's iouEval (addBatch, getMetricRight), imageops.relabel_city against
+    the reference's relabel cascade on all 256 byte values, and the colour table: tests/golden/misc.npz (make_golden_misc.py)"""
+    from glomeruli_segmentation_amd import imageops, segment
+    z = load_golden("misc.npz")
+    total = np.zeros((5, 5), dtype=np.int64)
+    for k in range(3):
+        h = segment.confusion(z["pred_%d" % k].ravel(), z["gt_%d" % k].ravel(), 5)
+        assert np.array_equal(h, z["hist_%d" % k]), k
+        total += h
+    assert np.array_equal(total, z["total_hist"])
+    o, pa, pi, m = segment.metric_right(total)
+    assert o == float(z["overall_acc"]) and m == float(z["miou"])
+    assert np.array_equal(pa, z["per_class_acc"]) and np.array_equal(pi, z["per_class_iu"])
+    assert np.array_equal(imageops.relabel_city(z["relabel_in"]), z["relabel_out"])
+    assert np.array_equal(imageops.PALETTE, z["palette"])
+
+
 def test_image_helpers():
     from glomeruli_segmentation_amd import imageops
     rng = np.random.default_rng(0)
