@@ -507,6 +507,14 @@ def test_cabi_argument_and_device_errors_without_gpu(sd1):
     assert lib.gs_conv2d_nhwc(None, 1, 8, 8, 3, None, 3, 3, 4, None, 1, 1, 0, None, None) == 1
     assert lib.gs_nms(None, None, 0, ctypes.c_float(0.5), ctypes.c_float(0.0), 10, None, None, None) == 1
     assert lib.gs_crop_preprocess(None, 4, 4, None, None, 8, 8, None, None) == 1
+    # the round-3 entries validate before they touch a device: null model list, bad network size, nothing to compute
+    f3 = (ctypes.c_float * 3)(1.0, 1.0, 1.0)
+    assert lib.gs_espnet_segment_crops_host(None, 1, None, None, None, 1, f3, f3, 512, 1024, 32, None, None, None, None, None, None) == 1
+    assert b"null" in lib.gs_last_error()
+    assert lib.gs_espnet_segment_crops(None, 0, None, None, 1, f3, f3, 512, 1024, None, None, None, None, None) == 1
+    assert lib.gs_espnet_ensemble_segment_crops(None, 0, None, None, 1, f3, f3, 512, 1024, None, None, None, None, None) == 1
+    assert lib.gs_detector_detect_host(None, None, 1, 64, 64, 1, None, None, None, None) == 1
+    assert lib.gs_abi_version() == _lib.ABI_VERSION and lib.gs_build_flags() == 0          # the product build: no GS_DIAG
     import torch
     if not torch.cuda.is_available():
         rc = lib.gs_espnet_create(blob.ctypes.data_as(ctypes.c_void_p), table, len(table), 5, 2, 8, 0, ctypes.byref(h))
