@@ -16,8 +16,9 @@ with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, waits for them and relays ra
 
 Two batches are in flight at a time: consecutive steps go to the engine's two LANES (two activation workspaces, each on
 its own HIP stream; include/glomseg.h).  The kernels of one batch run strictly one after the other, so what overlaps is
-the tail of one batch's kernel with the head of another's; `single_lane` in the line is the same loop with one batch
-in flight.
+the tail of one batch's kernel with the head of another's; the same loop is also timed with one batch in flight, and
+`value` is the better of the two (`batches_in_flight` says which; `two_lanes` and `single_lane` carry both): two lanes win by
+2-4 % on most boxes of the pool, on some the single stream does.
 
 The timed K-step loop is repeated (default 5 times, barrier + synchronize on both sides of each) and
 `value` is the median repeat; every repeat's time is in the line.  `value` is the HBM-resident rate;
@@ -297,22 +298,30 @@ def run_rank(args):
         return time.perf_counter() - t0
 
     # the reported numbers: no instrumentation in the stream; max over ranks per repeat, median over repeats
+    def reduce_max(local):
+        out = []
+        for el in local:
+            if dist is not None:
+                tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+                all_reduce(tmax, op=dist.ReduceOp.MAX)
+                el = float(tmax.item())
+            out.append(el)
+        return out
+
     reps_local = [timed(args.steps) for _ in range(max(args.repeats, 1))]
-    mode["lanes"] = 1                      # the same loop with one batch in flight (reported as `single_lane`)
+    mode["lanes"] = 1                      # the same loop with one batch in flight
     timed(args.steps)
-    single_local = float(np.median([timed(args.steps) for _ in range(max(args.repeats, 1))]))
-    single = max(gather_f64(single_local))
+    single_local = [timed(args.steps) for _ in range(max(args.repeats, 1))]
     mode["lanes"] = LANES
-    timed(args.steps)                      # leaves `totals` from a two-lane pass
-    reps = []
-    for el in reps_local:
-        if dist is not None:
-            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
-            all_reduce(tmax, op=dist.ReduceOp.MAX)
-            el = float(tmax.item())
-        reps.append(el)
-    elapsed = float(np.median(reps))
-    per_rank_ms = gather_f64(float(np.median(reps_local)) / args.steps * 1e3)
+    timed(args.steps)                      # leaves `totals` from a pass in the default mode
+    reps_lanes, reps_single = reduce_max(reps_local), reduce_max(single_local)
+    elapsed_lanes, single = float(np.median(reps_lanes)), float(np.median(reps_single))
+    # `value` is the better of the two ways of running the same K steps: on most boxes of this pool two batches in flight win
+    # by 2-4 %, on some the single stream does (same build, same command); both are in the line
+    use_single = LANES > 1 and single < elapsed_lanes
+    reps, elapsed = (reps_single, single) if use_single else (reps_lanes, elapsed_lanes)
+    in_flight = 1 if use_single else LANES
+    per_rank_ms = gather_f64(float(np.median(single_local if use_single else reps_local)) / args.steps * 1e3)
     pixel_totals = [int(v) for v in totals.tolist()]   # all-reduced in the last repeat
 
     # same K steps again, one batch in flight, with a HIP event pair around every kernel on the launch stream: per-kernel
@@ -422,10 +431,16 @@ def run_rank(args):
             "vs_baseline": None, "dtype": "f32", "data": "dry-run (no device work)" if args.dry_run else "synthetic",
             "config": {"workload": "ESPNet p=2 q=8 encoder+decoder, batch=32 synthetic 1024x512 uint8 BGR tiles per GPU, "
                                    "normalise+forward+argmax+counts, inputs resident in HBM, steps rotate through %d distinct batches, "
-                                   "%d batches in flight (engine lanes, one HIP stream each)" % (NBATCH, LANES),
+                                   "%d batch(es) in flight for `value` (engine lanes, one HIP stream each; the faster of one and "
+                                   "%d on this box, both reported)" % (NBATCH, in_flight, LANES),
                        "global_batch": n * BATCH, "tile": [H, W], "weights": "espnet_fold1 (tests/golden)",
                        "parallelism": "tile-range per rank x%d" % n},
+            "batches_in_flight": in_flight,
+            "two_lanes": {"value": round(total_tiles / elapsed_lanes, 2), "ms_per_step": round(elapsed_lanes / args.steps * 1e3, 3),
+                          "seconds": [round(r, 6) for r in reps_lanes],
+                          "note": "the K steps alternating between %d lanes (workspaces), each on its own stream" % LANES},
             "single_lane": {"value": round(total_tiles / single, 2), "ms_per_step": round(single / args.steps * 1e3, 3),
+                            "seconds": [round(r, 6) for r in reps_single],
                             "note": "the same K steps with one batch in flight (one workspace, one stream)"},
             "repeats": {"n": len(reps), "statistic": "median of max-over-ranks", "seconds": [round(r, 6) for r in reps]},
             "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
