@@ -1,10 +1,11 @@
 """Class map -> polygons -> labelme-style JSON: the per-crop export of
 module/espnet/test/VisualizeResults_iou.py:161-182 over module/common/boundary_extractor.py.
 
-The contour tracer and the polygon simplifier are host functions of libglomseg.so restated from the
-published algorithms (cv2 is not installed): parity with cv2.findContours / approxPolyDP point for
-point is unpinned, the tests pin geometric invariants (closed borders on the class boundary, hole
-detection, epsilon bound of the simplification).
+The contour tracer, the arc length and the polygon simplifier are host functions of libglomseg.so (csrc/contours.cpp)
+restated from the published algorithms of OpenCV 4.3 (cv2 is not installed).  They are checked point for point -- contour
+count, list order, start point, direction, every point and every polygon vertex -- against oracle/contour_oracle.py, a
+second restatement written independently of the C++ (tests/test_contour_oracle.py); cv2's own output cannot be produced
+on this stack.
 """
 import ctypes
 import json

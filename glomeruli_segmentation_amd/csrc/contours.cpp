@@ -2,7 +2,8 @@
 // cv2.findContours(thresh, RETR_LIST, CHAIN_APPROX_SIMPLE) + cv2.arcLength + cv2.approxPolyDP in
 // module/common/boundary_extractor.py:33-47.  OpenCV is not installed, so both are restated from the published
 // algorithms: Suzuki & Abe (1985) border following with 8-connectivity, and Ramer-Douglas-Peucker on a closed curve.
-// Parity with cv2 itself is unpinned; the tests pin geometric invariants instead.
+// Checked point for point (order, start point, direction, vertex lists) against oracle/contour_oracle.py, a second restatement
+// of OpenCV 4.3's functions written independently of this file (tests/test_contour_oracle.py); cv2 itself cannot run here.
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -41,7 +42,10 @@ void follow(std::vector<int> &f, int W, int x0, int y0, int from_dir, int nbd, s
     int x2 = x0 + DX[s], y2 = y0 + DY[s];   // (i1,j1) of the paper; becomes the "previous" point
     int x3 = x0, y3 = y0;                   // current point
     const int xl = x2, yl = y2;             // to recognise the end of the border
-    int prev_dir = -1;
+    // OpenCV starts with "the direction we arrived by" = opposite of the first clockwise hit (icvFetchContour: prev_s = s ^ 4),
+    // so a start pixel in the middle of a straight run (a hole whose left wall is a SW-NE diagonal through it) is not a
+    // CHAIN_APPROX_SIMPLE vertex; found by oracle/contour_oracle.py (round 4), -1 here wrote one point too many
+    int prev_dir = s ^ 4;
     for (;;) {
         // step 3.3: counter-clockwise search around the current point starting after the previous one
         int sd = 0;
@@ -139,14 +143,22 @@ gs_status gs_find_contours(const uint8_t *img, int h, int w, int simple, int *po
     return GS_OK;
 }
 
-// cv2.arcLength(curve, closed=True): perimeter of a closed polygon given as n (x,y) pairs.
+// cv2.arcLength(curve, closed=True): perimeter of a closed polygon given as n (x,y) pairs.  As cv::arcLength computes it
+// (shapedescr.cpp): every segment in float32 (points converted to Point2f, `float dx, dy`, float sqrt), summed in a double,
+// the closing segment last -> first taken FIRST.  The low bits matter: epsilon = 0.003 * this decides approxPolyDP's ties.
 double gs_arc_length_closed(const int *xy, int n)
 {
+    if (n <= 1)
+        return 0.0;
     double s = 0.0;
+    float px = (float)xy[2 * (n - 1)], py = (float)xy[2 * (n - 1) + 1];
     for (int i = 0; i < n; ++i) {
-        const int j = (i + 1) % n;
-        s += std::sqrt((double)(xy[2 * j] - xy[2 * i]) * (xy[2 * j] - xy[2 * i]) +
-                       (double)(xy[2 * j + 1] - xy[2 * i + 1]) * (xy[2 * j + 1] - xy[2 * i + 1]));
+        const float qx = (float)xy[2 * i], qy = (float)xy[2 * i + 1];
+        const float dx = qx - px, dy = qy - py;
+        const float a = dx * dx, b = dy * dy;      // separate roundings: no fused multiply-add across them
+        s += (double)std::sqrt(a + b);
+        px = qx;
+        py = qy;
     }
     return s;
 }
@@ -160,7 +172,7 @@ double gs_arc_length_closed(const int *xy, int n)
 //      contour order starting at the cut), distance test |cross| ^ 2 <= eps^2 * |chord|^2, ties to the first farthest point;
 //   3. a clean-up pass over the result that drops a vertex lying within sqrt(0.5) * eps of the chord of its neighbours when
 //      that chord is neither horizontal nor vertical and the vertex does not fold back.
-// Parity with cv2 proper stays unpinned (no cv2 output exists here); the invariants are tested in tests/test_host_logic.py.
+// Equality with the independent restatement in oracle/contour_oracle.py is tested in tests/test_contour_oracle.py.
 int gs_approx_poly_closed(const int *xy, int n, double epsilon, int *out)
 {
     if (n <= 0)
