@@ -104,6 +104,7 @@ struct ConvArgs {
     int N, H, W;   // OUTPUT size
     int strips;    // pixel strips per output row
     int total_tasks;
+    int wu;        // waves of a workgroup that take tasks (launch_conv_mfma: WAVES unless the launch has fewer tasks than wave slots)
 };
 
 typedef unsigned u32x3_t __attribute__((ext_vector_type(3)));
@@ -115,7 +116,9 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int N, int AUX = 0>
 __device__ __forceinline__ void buf_load_vec(const __amdgpu_buffer_rsrc_t &rs, int voff, int soff, float *dst)
 {
-    if constexpr (N == 2) {
+    if constexpr (N == 1) {   // (only instantiated, never run: one-pixel-per-lane forms do not use the vector mapping)
+        dst[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, AUX));
+    } else if constexpr (N == 2) {
         const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX);
         const unsigned e0 = v[0], e1 = v[1];
         dst[0] = __builtin_bit_cast(float, e0);
@@ -140,7 +143,9 @@ __device__ __forceinline__ void buf_load_vec(const __amdgpu_buffer_rsrc_t &rs, i
 template <int N, int AUX = 0>
 __device__ __forceinline__ void buf_store_vec(const __amdgpu_buffer_rsrc_t &rs, int voff, const float *src)
 {
-    if constexpr (N == 2) {
+    if constexpr (N == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, src[0]), rs, voff, 0, AUX);
+    } else if constexpr (N == 2) {
         u32x2_t v;
         v[0] = __builtin_bit_cast(unsigned, src[0]);
         v[1] = __builtin_bit_cast(unsigned, src[1]);
@@ -345,19 +350,25 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
     // the waves of one XCD therefore work on neighbouring rows of the same image(s), so the taps
     // they share stay in that XCD's 4 MiB L2 (with one contiguous range per wave every image of the
     // eighth was live at once and half of the B-operand L2 requests went on to the Infinity Cache).
+    // A launch with fewer tasks than wave slots (small batches) is SPREAD: only the first a.wu waves of a workgroup take tasks --
+    // waves 0..3 sit on four different SIMDs -- and the grid covers as many CUs as there are tasks for, so that a task has a
+    // matrix pipe to itself instead of sharing it while three quarters of the chip idle.  The spare waves only help stage.
     const int NB = gridDim.x;
+    const int wu = a.wu;
     int t0, t1, tstride;
     if ((NB & 7) == 0) {
         const int xcd = blockIdx.x & 7, per = NB >> 3;
         const int c0 = (int)((long long)a.total_tasks * xcd / 8), c1 = (int)((long long)a.total_tasks * (xcd + 1) / 8);
-        t0 = c0 + (blockIdx.x >> 3) * WAVES + wid;
+        t0 = c0 + (blockIdx.x >> 3) * wu + wid;
         t1 = c1;
-        tstride = per * WAVES;
+        tstride = per * wu;
     } else {
-        t0 = blockIdx.x * WAVES + wid;
+        t0 = blockIdx.x * wu + wid;
         t1 = a.total_tasks;
-        tstride = NB * WAVES;
+        tstride = NB * wu;
     }
+    if (wid >= wu)
+        t0 = t1;
     const long long wg = (long long)blockIdx.x * WAVES + wid;   // global wave id (diagnostic stamps)
     const int tasks_per_img = a.H * a.strips;
     bool staged = false;
@@ -937,9 +948,17 @@ gs_status launch_conv_mfma(ConvArgs a, int num_cus, hipStream_t stream)
         per_cu = li.per_cu;
     }
     int grid = num_cus * per_cu;
-    const int need = cdiv(a.total_tasks, WAVES);
-    if (grid > need) grid = need;
     if (grid >= 8) grid = grid / 8 * 8;
+    a.wu = WAVES;
+    if ((long long)a.total_tasks < (long long)grid * WAVES) {
+        // fewer tasks than wave slots: as few waves per workgroup as cover the tasks on all CUs, then as many workgroups
+        // as that needs (a whole multiple of 8, rounded UP: a wave with two tasks would double the launch)
+        a.wu = cdiv(a.total_tasks, grid);
+        if (a.wu < 1) a.wu = 1;
+        int g = cdiv(a.total_tasks, a.wu);
+        if (g >= 8) g = (g + 7) / 8 * 8;
+        grid = g < grid ? g : grid;
+    }
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, a);
     GS_HIP(hipGetLastError());

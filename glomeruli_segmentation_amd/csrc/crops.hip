@@ -424,6 +424,11 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
     if (st != GS_OK) return st;
     if (batch > MAXC) batch = MAXC;
     if (batch > n_crops) batch = n_crops;
+    // A short list -- one slide's crops (56 on the example slide, 7 per rank on eight GPUs) -- is cut into four batches of at
+    // least eight crops rather than one or two full ones: the first batch's upload and the last one's download are exposed,
+    // and since round 4 the forward keeps ~90 % of its full-batch rate down to 14-16 tiles (profiles/r04_latency.json)
+    if (n_crops < 4 * batch)
+        batch = std::max(std::min(batch, 8), (n_crops + 3) / 4);
     for (int i = 0; i < n_crops; ++i) {
         GS_REQUIRE(crops[i] && (!masks || masks[i]), "crop %d: null pointer", i);
         GS_REQUIRE(heights[i] > 0 && widths[i] > 0 && (long long)heights[i] * widths[i] < (1ll << 29), "crop %d has a bad size %dx%d", i,

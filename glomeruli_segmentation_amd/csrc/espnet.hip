@@ -55,6 +55,10 @@ void set_error(const char *fmt, ...)
 #define CFG_L3_BR_P2     32, 8,   26,  9,   1,     5,   28,   25,   2, 13
 #define CFG_L3_BR_P2F    32, 8,   26,  9,   1,     5,   28,   25,   2, 3    // with the fused 1x1: 32 more accumulators
 #define CFG_L3_BR_P2R    32, 8,   26,  9,   1,     5,   28,   25,   2, 13   // shipped fused ESP form: a third of a dilation in flight
+// small batches (launches with fewer tasks than SIMDs): 32-pixel strips -- the same accumulation chain per pixel, four /
+// two times the tasks (forward_impl picks the shape per launch from the task count; tools/latency.py)
+#define CFG_L3_BR_P1R    32, 8,   26,  9,   1,     5,   28,   25,   1, 13
+#define CFG_L3_C1S_BNL_P1 32, 8,  132, 9,   2,     1,   25,   25,   1, L3C1S_BNL_G
 #define CFG_DEC_CONV     16, 8,   24,  9,   1,     1,   5,    5,    8, 3
 #define CFG_DEC_CONV_XM  16, 8,   24,  3,   1,     1,   5,    5,    8, 6
 
@@ -770,6 +774,10 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     set_stage("b2", m->a1, 131);
 
     // ---- level 3 (Model.py:361-366)
+    // Small batches: a half-row task per SIMD does not fill the chip below 8 tiles (64 rows x 2 strips x n tasks for 1024
+    // SIMDs); with 32-pixel strips (one pixel per lane, the same accumulation chain per pixel: same bits) there are twice as
+    // many, each half as long.  Used while even those leave SIMDs without a task.
+    const bool small3 = (long long)n * H3 * cdiv(W3, 64) * 2 <= (long long)m->num_cus * 4 && !no_vec();
     int rd3 = 0;
     L.run(K_L3_C1S, px3 * (131 * 9 * 25 * 2), [&] {
 #ifdef GS_DIAG
@@ -780,6 +788,10 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             ConvArgs ca = conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n);
             ca.bnl_s0 = 64 / 2;      // k-groups of two channels
             ca.bnl_s1 = 128 / 2;
+            // whole-row tasks (128 pixels) are one per wave at batch 32; below a quarter of that the row is cut into 32-pixel
+            // tasks (batch 1: 64 -> 256 tasks, 0.180 -> see profiles/r04_latency.json)
+            if ((long long)n * H3 * cdiv(W3, 128) * 4 <= (long long)m->num_cus * 8)
+                return launch_conv_mfma<CFG_L3_C1S_BNL_P1, F_S2PAIR | POL_L3_C1S | S2FLIP_L3 | F_BNLOAD>(ca, m->num_cus, s);
             return launch_conv_mfma<CFG_L3_C1S_BNL, F_S2PAIR | POL_L3_C1S | S2FLIP_L3 | F_BNLOAD>(ca, m->num_cus, s);
         }
         return launch_conv_mfma<CFG_L3_C1S, F_S2PAIR | POL_L3_C1S | AGL_S2 | S2FLIP_L3>(conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n), m->num_cus, s);
@@ -787,6 +799,8 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     L.run(K_L3_DOWN, px3 * (25 * 9 * 128 * 2) + (m->l3_0.fused_next ? px3 * (128 * 25 * 2) : 0), [&] {
         ConvArgs ca = conv_args(m->r3[rd3], wb + m->l3_0.br, m->cc[0], nullptr, n);
         if (m->l3_0.fused_next) {   // no residual here: the four-pixel vector mapping still fits with the second accumulator set
+            if (small3)
+                return launch_conv_mfma<CFG_L3_BR_P1R, F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3 | SKIP_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
 #if CFG_L3_DOWN_P2
             if (ca.W % 2 == 0 && !no_vec())
                 return launch_conv_mfma<CFG_L3_BR_P2R, F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3 | F_VEC | SKIP_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
@@ -817,6 +831,8 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
                 return diag_l3_variants(m, ca, i, s);
 #endif
             if (fuse_next) {
+                if (small3)   // (one pixel per lane: a whole slot's residual fits in registers, requested a dilation ahead)
+                    return launch_conv_mfma<CFG_L3_BR_P1R, F_BNACT | F_RES | POL_L3_ESP | AGL_L3 | FUSE_L3 | SKIP_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
 #if CFG_L3_FUSE_P4
                 // four pixels per lane with the residual through a half-slot register ring (round 2's first fused form)
                 if (ca.W % 4 == 0 && !no_vec())
@@ -830,6 +846,8 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
                     return launch_conv_mfma<CFG_L3_BR_P2R, F_BNACT | F_RES | F_RES_RING | F_VEC | POL_L3_ESP | AGL_L3 | FUSE_L3 | SKIP_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
                 return launch_conv_mfma<CFG_L3_BR_P2F, F_BNACT | F_RES | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
             }
+            if (small3)
+                return launch_conv_mfma<CFG_L3_BR_P1R, F_BNACT | F_RES | POL_L3_ESP | AGL_L3 | SKIP_L3>(ca, m->num_cus, s);
 #if CFG_L3_LAST_P2
             // the last (unfused) block in the half-row task shape of the fused ones, tap rows in the halo skipped
             if (ca.W % 2 == 0 && !no_vec())
@@ -858,7 +876,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         a.out = view(m->o2c);
         a.enc_logits = m->encoder_only ? logits : nullptr;
         a.N = n;
-        hipLaunchKernelGGL(dec1_kernel<CLS>, dim3(blocks_for((long long)n * H3 * W3)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((dec1_kernel<CLS, 16>), dim3((unsigned)(((long long)n * H3 * W3 + 63) / 64)), dim3(256), 0, s, a);
         return GS_OK;
     });
     if (m->encoder_only)
@@ -878,7 +896,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         a.br = wb + m->cbr0;
         a.t = view(m->tt);
         a.N = n;
-        hipLaunchKernelGGL(dec2_kernel<CLS>, dim3(blocks_for((long long)n * H2 * W2)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(dec2_kernel<CLS>, dim3((unsigned)(((long long)n * H2 * W2 + 63) / 64)), dim3(256), 0, s, a);   // 64 pixels x 4 channel quarters
         return GS_OK;
     });
     set_stage("combine_t", m->tt, 2 * CLS);

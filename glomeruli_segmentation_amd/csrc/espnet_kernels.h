@@ -2,6 +2,7 @@
 // names the reference lines it fuses.  Weights are read with wave-uniform indices, so hipcc emits
 // scalar (SMEM) loads for them; activations are read coalesced along x.
 #pragma once
+#include <type_traits>
 #include "gs_internal.h"
 
 namespace gs {
@@ -341,13 +342,24 @@ struct Dec1Args {
     int N;
 };
 
-template <int CLS>
+// A workgroup = 64 pixels x 4 waves: wave w sums channels 64w .. 64w+63 of its lane's pixel, the four partial sums meet in
+// LDS and are added as (q0 + q1) + (q2 + q3) -- at every batch size, so a tile's bits do not depend on the batch.  (Round 3
+// summed the 256 channels in one chain per thread: at one tile that chain is the kernel -- 0.036 ms, 140 ns per channel
+// whatever the constants came from (scalar loads, LDS, v_readlane: all measured) -- every load of a wave touches another
+// channel plane, 33 KB from the last.)  Batches of CB channels: all their loads are issued before the first use, and the
+// PReLU is written max/min so that it stays straight-line (as `v > 0 ? v : alpha * v` hipcc branched around the scalar load
+// of alpha, which put one full memory round trip per channel on the critical path).
+template <int CLS, int CB>
 __global__ void __launch_bounds__(256) dec1_kernel(const Dec1Args a)
 {
     const int H3 = a.c0.H, W3 = a.c0.W;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)a.N * H3 * W3)
-        return;
+    __shared__ float part[3][CLS][64];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long total = (long long)a.N * H3 * W3;
+    long long idx = (long long)blockIdx.x * 64 + lane;
+    const bool active = idx < total;
+    if (!active)
+        idx = total - 1;    // (every thread reaches the barrier; it computes a pixel again and stores nothing)
     const int x = (int)(idx % W3);
     const int y = (int)((idx / W3) % H3);
     const int n = (int)(idx / ((long long)W3 * H3));
@@ -355,29 +367,24 @@ __global__ void __launch_bounds__(256) dec1_kernel(const Dec1Args a)
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = 0.0f;
-    // output2_0 and output2 share one layout (both are level-3 ping-pong buffers)
+    // output2_0 (channels 0..127) and output2 (128..255) share one layout (both are level-3 ping-pong buffers)
     const long long pix = (long long)n * a.c0.sn + a.c0.off + y * a.c0.pitch + x;
-    // Batches of 16 channels: all 16 activation loads are issued before the first use, and the PReLU is
-    // written max/min so that it stays straight-line (as `v > 0 ? v : alpha * v` hipcc branched around the
-    // scalar load of alpha, which put one full memory round trip per channel on the critical path: 256 in a
-    // row, 0.141 ms for a 0.29 GB stream).
-    constexpr int CB = 16;
+    const float *plane0 = (w < 2 ? a.c0.base : a.clast.base) + pix + (long long)((w & 1) * 64) * a.c0.sc;
     auto fetch = [&](int c0, float *dst) {
-        const float *src = (c0 < 128 ? a.c0.base : a.clast.base) + pix + (long long)(c0 & 127) * a.c0.sc;
 #pragma unroll
         for (int j = 0; j < CB; ++j)
-            dst[j] = ld_stream<NT_DEC1_LD>(src + (long long)j * a.c0.sc);
+            dst[j] = ld_stream<NT_DEC1_LD>(plane0 + (long long)(c0 + j) * a.c0.sc);
     };
     float cur[CB], nxt[CB];
     fetch(0, cur);
-    for (int c0 = 0; c0 < 256; c0 += CB) {
-        if (c0 + CB < 256)
+    for (int c0 = 0; c0 < 64; c0 += CB) {
+        if (c0 + CB < 64)
             fetch(c0 + CB, nxt);   // the next batch is in flight while this one is consumed
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < CB; ++j) {
             // per-channel constants packed [c][8] = {scale, shift, alpha, w[0..CLS)}: one scalar load per channel
-            const float *pc = a.b3w + (c0 + j) * 8;
+            const float *pc = a.b3w + (w * 64 + c0 + j) * 8;
             const float t = cur[j] * pc[0] + pc[1];
             const float v = prelu(t, pc[2]);
 #pragma unroll
@@ -388,6 +395,17 @@ __global__ void __launch_bounds__(256) dec1_kernel(const Dec1Args a)
         for (int j = 0; j < CB; ++j)
             cur[j] = nxt[j];
     }
+    if (w > 0) {
+#pragma unroll
+        for (int k = 0; k < CLS; ++k)
+            part[w - 1][k][lane] = s[k];
+    }
+    __syncthreads();
+    if (w > 0 || !active)
+        return;
+#pragma unroll
+    for (int k = 0; k < CLS; ++k)
+        s[k] = (s[k] + part[0][k][lane]) + (part[1][k][lane] + part[2][k][lane]);
     if (a.enc_logits) {
 #pragma unroll
         for (int k = 0; k < CLS; ++k)
@@ -431,13 +449,20 @@ struct Dec2Args {
     int N;
 };
 
+// A workgroup = 64 pixels x 4 waves, as dec1_kernel: wave w sums channels 32w .. 32w+31 (wave 3 goes on through 128..130), the
+// partial sums are added as (q0 + q1) + (q2 + q3) at every batch size.  A wave's 32 channels are all raw or all normalised
+// (raw_c0 = 64, raw_cn = 0 or 64: checked by the caller), so the BN + PReLU of the lazy b2 is a wave-uniform choice.
 template <int CLS>
 __global__ void __launch_bounds__(256) dec2_kernel(const Dec2Args a)
 {
     const int H2 = a.a1.H, W2 = a.a1.W;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)a.N * H2 * W2)
-        return;
+    __shared__ float part[3][CLS][64];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long total = (long long)a.N * H2 * W2;
+    long long idx = (long long)blockIdx.x * 64 + lane;
+    const bool active = idx < total;
+    if (!active)
+        idx = total - 1;    // (every thread reaches the barrier)
     const int x = (int)(idx % W2);
     const int y = (int)((idx / W2) % H2);
     const int n = (int)(idx / ((long long)W2 * H2));
@@ -445,32 +470,47 @@ __global__ void __launch_bounds__(256) dec2_kernel(const Dec2Args a)
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = 0.0f;
-    // (three plain loops, so that each keeps its loads batched: a range test inside one loop cost 0.045 ms)
-    const int r0 = a.raw_cn > 0 ? a.raw_c0 : 131, r1 = a.raw_cn > 0 ? a.raw_c0 + a.raw_cn : 131;
-#pragma unroll 8
-    for (int c = 0; c < r0; ++c) {
-        const float v = ld_stream<NT_DEC2_LD>(at(a.a1, n, c, y, x));
-        const float *pc = a.w3c + c * 8;   // level3_C weights packed [c][8]: one scalar load per channel
+    const int cb = 32 * w;
+    if (cb >= a.raw_c0 && cb < a.raw_c0 + a.raw_cn) {   // (uniform) lazy b2: these planes are raw; BN + PReLU of the cat's BR here
+#pragma unroll 16
+        for (int c = cb; c < cb + 32; ++c) {
+            const float v = bn_prelu(ld_stream<NT_DEC2_LD>(at(a.raw, n, c - a.raw_c0, y, x)), a.b2, 131, c);
+            const float *pc = a.w3c + c * 8;   // level3_C weights packed [c][8]: one scalar load per channel
+#pragma unroll
+            for (int k = 0; k < CLS; ++k)
+                s[k] = fmaf(pc[k], v, s[k]);
+        }
+    } else {
+#pragma unroll 16
+        for (int c = cb; c < cb + 32; ++c) {
+            const float v = ld_stream<NT_DEC2_LD>(at(a.a1, n, c, y, x));
+            const float *pc = a.w3c + c * 8;
+#pragma unroll
+            for (int k = 0; k < CLS; ++k)
+                s[k] = fmaf(pc[k], v, s[k]);
+        }
+    }
+    if (w == 3) {
+#pragma unroll
+        for (int c = 128; c < 131; ++c) {
+            const float v = ld_stream<NT_DEC2_LD>(at(a.a1, n, c, y, x));
+            const float *pc = a.w3c + c * 8;
+#pragma unroll
+            for (int k = 0; k < CLS; ++k)
+                s[k] = fmaf(pc[k], v, s[k]);
+        }
+    }
+    if (w > 0) {
 #pragma unroll
         for (int k = 0; k < CLS; ++k)
-            s[k] = fmaf(pc[k], v, s[k]);
+            part[w - 1][k][lane] = s[k];
     }
-#pragma unroll 8
-    for (int c = r0; c < r1; ++c) {      // lazy b2: these planes are raw; BN + PReLU of the cat's BR here
-        const float v = bn_prelu(ld_stream<NT_DEC2_LD>(at(a.raw, n, c - r0, y, x)), a.b2, 131, c);
-        const float *pc = a.w3c + c * 8;
+    __syncthreads();
+    if (w > 0 || !active)
+        return;
 #pragma unroll
-        for (int k = 0; k < CLS; ++k)
-            s[k] = fmaf(pc[k], v, s[k]);
-    }
-#pragma unroll 8
-    for (int c = r1; c < 131; ++c) {
-        const float v = ld_stream<NT_DEC2_LD>(at(a.a1, n, c, y, x));
-        const float *pc = a.w3c + c * 8;
-#pragma unroll
-        for (int k = 0; k < CLS; ++k)
-            s[k] = fmaf(pc[k], v, s[k]);
-    }
+    for (int k = 0; k < CLS; ++k)
+        s[k] = (s[k] + part[0][k][lane]) + (part[1][k][lane] + part[2][k][lane]);
     float tv[2 * CLS];
 #pragma unroll
     for (int k = 0; k < CLS; ++k) {

@@ -124,6 +124,23 @@ def test_batch_equals_single(torch_mod, engine1):
         assert torch.equal(ms[0], mb[i]) and torch.equal(hs[0], hb[i])
 
 
+def test_small_batch_task_shapes_give_the_same_bits(torch_mod, engine1):
+    """Below 8 / 16 tiles the level-3 launches cut rows into 32-pixel tasks, spread over the CUs one wave per SIMD, and dec1 /
+    dec2 fetch deeper (forward_impl, round 4).  Which wave computes a pixel changes; its accumulation chain must not: the
+    LOGITS of a full-size tile are the same bits at every batch size."""
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    torch = torch_mod
+    mean, std = FOLD_MEAN_STD[1]
+    tiles = torch.from_numpy(np.stack([synth_tile(100 + s) for s in range(20)])).cuda()
+    mb, hb, lb = engine1.segment(tiles, mean, std, want_logits=True)        # 20 tiles: the full-batch shapes
+    for n in (1, 2, 4, 5, 8, 9, 16):
+        ms, hs, ls = engine1.segment(tiles[:n], mean, std, want_logits=True)
+        assert torch.equal(ls, lb[:n]), n
+        assert torch.equal(ms, mb[:n]) and torch.equal(hs, hb[:n]), n
+        ms2, hs2, _ = engine1.segment(tiles[:n], mean, std)                 # the mask-only kernels (no logits written)
+        assert torch.equal(ms2, mb[:n]) and torch.equal(hs2, hb[:n]), n
+
+
 def test_noise_tiles_and_edge_sizes(torch_mod, engine1):
     """stress input (pure noise) at the smallest legal size and a ragged one, vs the oracle"""
     from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, noise_tile

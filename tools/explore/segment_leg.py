@@ -1,0 +1,41 @@
+"""Where one slide's segment + composite leg (56 crops of the example sizes) spends its time: compositor construction,
+the crop pipeline call (pageable / pinned crops, masks / counts only), the rest."""
+import os, sys, time
+import numpy as np
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tools"))
+from bench_slide import SynthSlide, grid_boxes
+from glomeruli_segmentation_amd.composite import SlideCompositor
+from glomeruli_segmentation_amd.engine import EspnetEngine
+from glomeruli_segmentation_amd.pipeline import segment_crops
+from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD
+
+S = 40000
+example = np.load(os.path.join(REPO, "tests", "golden", "merge.npz"))["example_boxes"]
+boxes = grid_boxes(S, example)
+slide = SynthSlide(S, S, boxes)
+mean, std = FOLD_MEAN_STD[1]
+z = np.load(os.path.join(REPO, "tests", "golden", "weights_fold1.npz"))
+eng = EspnetEngine({k: z[k] for k in z.files}, lanes=2)
+dev = eng.device
+crops = [np.ascontiguousarray(slide.read_region(b[0], b[1], b[2] - b[0], b[3] - b[1], 1.0)[:, :, ::-1]) for b in boxes]
+pinned = [torch.from_numpy(c).pin_memory() for c in crops]
+print("crops", len(crops), "MB in", sum(c.nbytes for c in crops) / 1e6)
+
+def t(f, n=5):
+    f(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter(); f(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2] * 1e3
+
+print("SlideCompositor(): %.2f ms" % t(lambda: SlideCompositor(S, S, dev)))
+comp = SlideCompositor(S, S, dev)
+org = [(b[0], b[1]) for b in boxes]
+for name, cr in (("pageable", crops), ("pinned", pinned)):
+    for batch in (56, 32, 28, 19, 14, 10):
+        # (a batch >= len/4 stops the library's own short-list rule from changing it)
+        print("%s crops, batch %2d, masks + paste: %.2f ms" % (name, batch, t(lambda: segment_crops(eng, cr[:], mean, std, 512, 1024, batch, paste=comp.paste_target(), origins=org, want_masks=True))))
+    print("%s crops, batch 14, counts + paste only: %.2f ms" % (name, t(lambda: segment_crops(eng, cr[:], mean, std, 512, 1024, 14, paste=comp.paste_target(), origins=org, want_masks=False))))
