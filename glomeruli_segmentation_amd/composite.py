@@ -148,8 +148,12 @@ def load_class_map(json_path):
 
 
 def build_parser():
-    """the prediction branch of eval_wsi_segmentation.py:397-422 (flags kept; the ground-truth evaluation flags are accepted
-    and must stay unset: GT tooling -- annotation XML, labelme shapes -- is outside the rebuilt path)."""
+    """argparse surface of eval_wsi_segmentation.py:397-422, every flag with the reference's dest and default.  The rebuilt
+    path is the prediction branch (:430-431, generate_pred_wsi).  There the reference itself never reads --iou_threshold,
+    --output_file, --start or --end (they are used by scan_files, the ground-truth branch, :108-118): they are accepted so
+    that the reference's command lines (README.md:268-281, example/README.md:108-133) run unchanged, and have no effect.  The
+    three ground-truth directories select the evaluation branch (:427-434), which needs the GT tooling that is out of scope
+    (annotation XML, labelme shapes): accepted by the parser, refused by main() with an explanation."""
     p = ArgumentParser(description='merge cropped glomerular segmented images')
     p.add_argument('--staining', dest='staining', type=str, required=True)
     p.add_argument('--merged_detection_result_csv', dest='input_csv', type=str, required=True)
@@ -159,6 +163,10 @@ def build_parser():
     p.add_argument('--object_detection_gt_xml_dir', dest='ob_gt_xml_dir', type=str, default=None)
     p.add_argument('--segmentation_gt_json_dir', dest='seg_gt_json_dir', type=str, default=None)
     p.add_argument('--segmentation_gt_png_dir', dest='gt_png_dir', type=str, default=None)
+    p.add_argument('--iou_threshold', dest='iou_threshold', type=float, default=0.01)
+    p.add_argument('--output_file', dest='output_file', type=str, default='./output/seg_data_pred/seg_data_output.tsv')
+    p.add_argument('--start', dest='start', type=int, default=0)
+    p.add_argument('--end', dest='end', type=int, default=0)
     p.add_argument('--output_dir', dest='output_dir', type=str, default='./output/seg_data_pred')
     p.add_argument('--window_size', dest='window_size', type=int, default=2400)
     p.add_argument('--classes', dest='classes', type=int, default=5)
@@ -239,9 +247,11 @@ def generate_pred_wsi(args, out=sys.stdout):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    if args.seg_gt_json_dir or args.gt_png_dir or args.ob_gt_xml_dir:
-        print("the ground-truth evaluation branch (annotation XML / labelme shapes) is outside the rebuilt path; "
-              "leave the *_gt_* arguments unset to compose the prediction WSI", file=sys.stderr)
+    # the reference takes the evaluation branch only when ALL three ground-truth directories are given (:427); with any of
+    # them missing it composes the prediction WSI and ignores the rest
+    if args.seg_gt_json_dir is not None and args.gt_png_dir is not None and args.ob_gt_xml_dir is not None:
+        print("the ground-truth evaluation branch (scan_files: annotation XML, labelme shapes, the TSV of --output_file) is outside "
+              "the rebuilt path; leave the three *_gt_* directories unset to compose the prediction WSI", file=sys.stderr)
         return 2
     generate_pred_wsi(args)
     return 0

@@ -334,14 +334,17 @@ def main(argv=None, detector=None):
         import torch
         torch.cuda.set_device(local if world > 1 and os.environ.get("GLOMSEG_ONE_GPU") != "1" else args.gpu_id)
         detector = own = load_detector(args.model, args.model_name, args.synthetic_weights)
+    from .shard import abort_rank, finish_ranks
     try:
         split_all(args, detector, rank, world, dist)
-    finally:
+    except BaseException:
         if own is not None:
             own.close()
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        abort_rank(dist)      # a rank that fails alone must not wait for its peers in a barrier (shard.abort_rank)
+        raise
+    if own is not None:
+        own.close()
+    finish_ranks(dist)
     return 0
 
 

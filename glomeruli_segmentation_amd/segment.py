@@ -250,7 +250,10 @@ def main(argv=None):
         print('Pre-trained model file does not exist. Please check the --weights path')
         return -1
     if args.gpu_id < 0:
-        print("this build runs the ESPNet forward on a HIP device only: pass --gpu_id >= 0", file=sys.stderr)
+        # the reference's default: --gpu_id -1 = CPU (VisualizeResults_iou.py:252-255,302).  This build has no CPU product path
+        # -- a silent fallback would be a different program answering under the same name -- so the default is refused, loudly
+        print("--gpu_id %d selects the CPU in the reference (its default); this build runs the ESPNet forward on a HIP device "
+              "only and has no CPU path: pass --gpu_id >= 0" % args.gpu_id, file=sys.stderr)
         return 2
     import torch
     from .engine import EspnetEngine
@@ -271,13 +274,15 @@ def main(argv=None):
         engine = EspnetEngine(sd, classes=args.classes, p=args.p, q=args.q, encoder_only=True)
     else:
         engine = EspnetEngine(sd, classes=args.classes, p=args.p, q=args.q, lanes=2)
+    from .shard import abort_rank, finish_ranks
     try:
         evaluate(args, engine, rgb_list, label_list, rank, world, dist)
-    finally:
+    except BaseException:
         engine.close()
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        abort_rank(dist)      # a rank that fails alone must not wait for its peers in a barrier (shard.abort_rank)
+        raise
+    engine.close()
+    finish_ranks(dist)
     return 0
 
 

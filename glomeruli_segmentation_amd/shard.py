@@ -57,6 +57,31 @@ def init_from_env(use_gpu=True):
     return rank, world, local, dist
 
 
+def finish_ranks(dist):
+    """Success path of a sharded CLI: every rank has made the same collectives, so a barrier and the teardown are safe."""
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def abort_rank(dist):
+    """Failure path (call from an `except` block): this rank failed ALONE -- an unreadable image, a shape assert, out of memory --
+    while its peers sit in a gather / all-reduce.  A barrier here would be a collective the peers never reach: this rank would
+    block until the backend's timeout instead of exiting, and launch.spawn_ranks, which ends the job when a child exits
+    non-zero, would never see it.  So: print the traceback, skip barrier and teardown, leave with status 1 -- at once, without
+    interpreter shutdown (a process-group destructor may itself wait for the peers).  With one rank the exception just
+    propagates."""
+    if dist is None:
+        return
+    import os
+    import sys
+    import traceback
+    traceback.print_exc()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(1)
+
+
 def collective_device(dist, device=None):
     """the device tensors handed to `dist` must live on: the CPU for gloo, this rank's current GPU otherwise"""
     import torch

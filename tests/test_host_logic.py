@@ -541,6 +541,42 @@ def test_a_failing_rank_takes_the_job_down_quickly():
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]      # no result line from a broken job
 
 
+def test_a_rank_that_raises_inside_a_cli_ends_the_job(tmp_path):
+    """A sharded CLI whose rank 1 raises in its window loop while rank 0 goes on to the row gather: rank 1 must leave non-zero
+    at once (no barrier on the failure path, shard.abort_rank) so that spawn_ranks can end rank 0 -- with the barrier in a
+    `finally:` rank 1 sat in a collective its peer never reached, until the backend's timeout."""
+    import io
+    import time
+    from glomeruli_segmentation_amd import launch
+    data_dir, tl, _ = _png_slide_tree(tmp_path, W=8192, H=4096)
+    helper = os.path.join(REPO, "tests", "helpers", "detect_stub_rank.py")
+    argv = ["--target_list", tl, "--data_dir", data_dir, "--staining", "OPT_PAS", "--output_dir", str(tmp_path / "out"),
+            "--window_size", "500", "--overlap_ratio", "0.1", "--batch", "4"]
+    saved = {k: os.environ.get(k) for k in ("GLOMSEG_DIST_BACKEND", "GS_TEST_FAIL_RANK", "MASTER_PORT", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    try:
+        for k in ("MASTER_PORT", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            os.environ.pop(k, None)
+        os.environ["GLOMSEG_DIST_BACKEND"] = "gloo"
+        os.environ["GS_TEST_FAIL_RANK"] = "1"
+        out, err = io.StringIO(), io.StringIO()
+        t0 = time.time()
+        rc = launch.spawn_ranks(helper, argv, 2, out=out, err=err)
+        el = time.time() - t0
+        assert rc == 1 and el < 60.0, (rc, el, err.getvalue()[-800:])
+        assert "rank 1 of 2 exited with code 1" in err.getvalue() and "fails on purpose" in err.getvalue()
+        # and the same command line with nobody failing writes the one CSV
+        os.environ["GS_TEST_FAIL_RANK"] = "none"
+        os.environ.pop("MASTER_PORT", None)
+        rc = launch.spawn_ranks(helper, argv, 2, out=io.StringIO(), err=io.StringIO())
+        assert rc == 0 and os.path.isfile(tmp_path / "out" / "OPT_PAS_GlomusList.csv")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_rank_cpu_placement_follows_the_gpu_numa_node(tmp_path):
     """launch.rank_cpus on a fake sysfs: four GPUs, two per NUMA node; ranks share their node's allowed CPUs evenly"""
     from glomeruli_segmentation_amd import launch
@@ -672,3 +708,100 @@ def test_merge_cli(tmp_path):
     with pytest.raises(RuntimeError, match="openslide"):
         merge.main(["--staining", "OPT_PAS", "--target_list", str(tl), "--detected_list", str(det_csv), "--output_dir", str(tmp_path),
                     "--overlap_threshold", "0.35"])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the reference's documented command lines parse as they stand (example/README.md:25-133, README.md:226-281)
+def _argv(text):
+    """a README command block -> argv: the words after the script name, continuation backslashes dropped"""
+    import shlex
+    words = shlex.split(text.replace("\\\n", " "))
+    return words[2:]                      # drop `python <script>`
+
+
+def test_reference_readme_command_lines_parse():
+    from glomeruli_segmentation_amd import composite, detect, merge, segment
+    out = "/workspace/output"
+    # --- example/README.md:26-37, detect_glomus_test.py
+    a = detect.build_parser().parse_args(_argv("""python /opt/glomeruli_detection/detect_glomus_test.py \
+        --model=/workspace/fold_1 \
+        --target_list=/opt/ESPNet/example/opt_pas_test_list.txt \
+        --data_dir=/opt/ESPNet/example/data \
+        --staining=OPT_PAS \
+        --output_dir=%s \
+        --output_file_ext=_test1 \
+        --window_size=2000 \
+        --overlap_ratio=0.1 \
+        --conf_threshold=0.2 \
+        --model_name=frozen_inference_graph.pb""" % out))
+    assert (a.model, a.data_category, a.output_file_ext, a.window_size, a.overlap_ratio, a.conf_threshold, a.model_name) == \
+        ("/workspace/fold_1", "OPT_PAS", "_test1", 2000, 0.1, 0.2, "frozen_inference_graph.pb")
+    d = detect.build_parser().parse_args([])          # defaults of detect_glomus_test.py:390-403
+    assert (d.data_category, d.output_dir, d.output_file_ext, d.window_size, d.overlap_ratio, d.conf_threshold) == \
+        ("OPT_PAM", "./output", "_GlomusList", None, None, 0.6)
+    # --- example/README.md:40-49, merge_overlaped_glomus.py
+    a = merge.build_parser().parse_args(_argv("""python /opt/glomeruli_detection/merge_overlaped_glomus.py \
+        --target_list=/opt/ESPNet/example/opt_pas_test_list.txt \
+        --detected_list=/workspace/output/OPT_PAS_test1.csv \
+        --data_dir=/opt/ESPNet/example/data \
+        --staining=OPT_PAS \
+        --output_dir=/workspace/output \
+        --output_file_ext=test1 \
+        --conf_threshold=0.9 \
+        --overlap_threshold=0.35"""))
+    assert (a.input_file, a.annotation_dir, a.training_type, a.conf_threshold, a.overlap_threshold) == \
+        ("/workspace/output/OPT_PAS_test1.csv", "/opt/ESPNet/example/data", "test1", 0.9, 0.35)
+    # --- example/README.md:75-104 (both forms) and README.md:226-239, VisualizeResults_iou.py
+    for label in ("--label_data_dir=%s/seg_data/label/all \\\n" % out, ""):
+        a = segment.build_parser().parse_args(_argv("""python /opt/ESPNet/test/VisualizeResults_iou.py \
+            --classes=5 \
+            --rgb_data_dir=%s/seg_data/org_image \
+            %s--savedir=%s/seg_data_pred \
+            --weights=/opt/ESPNet/models/espnet_fold1.pth \
+            --gpu_id=0 \
+            --decoder \
+            --img_extn=PNG \
+            --colored \
+            --overlay \
+            --mean 204.60071 170.19359 199.57469 \
+            --std 20.61257 42.92207 28.401505""" % (out, label, out)))
+        assert a.classes == 5 and a.gpu_id == 0 and a.decoder and a.colored and a.overlay and not a.cityFormat
+        assert a.mean == ["204.60071", "170.19359", "199.57469"] and a.std == ["20.61257", "42.92207", "28.401505"]
+        assert (a.label_data_dir is not None) == bool(label)
+    a = segment.build_parser().parse_args(_argv("""python /opt/ESPNet/test/VisualizeResults_iou.py \
+        --classes 5 --rgb_data_dir d --label_data_dir l --savedir s --weights /models/espnet_fold1.pth --gpu_id 0 --img_extn PNG \
+        --mean 204.60071 170.19359 199.57469 --std 20.61257 42.92207 28.401505 --decoder --colored --overlay --cityFormat"""))
+    assert a.cityFormat and a.img_extn == "PNG"
+    d = segment.build_parser().parse_args(["--rgb_data_dir", "d", "--weights", "w", "--mean", "1", "2", "3", "--std", "1", "2", "3"])
+    assert (d.inWidth, d.inHeight, d.scaleIn, d.modelType, d.savedir, d.gpu_id, d.p, d.q, d.classes, d.img_extn) == \
+        (1024, 512, 1, 1, "./results", -1, 2, 8, 5, "PNG")          # VisualizeResults_iou.py:295-315
+    # --- example/README.md:108-133, eval_wsi_segmentation.py (with and without the ground-truth directories)
+    gt = ("--segmentation_gt_json_dir=/opt/ESPNet/example/data/seg_annotation \\\n"
+          "--object_detection_gt_xml_dir=/opt/ESPNet/example/data \\\n--segmentation_gt_png_dir=/opt/ESPNet/example/data/label \\\n")
+    for extra in (gt, ""):
+        a = composite.build_parser().parse_args(_argv("""python /opt/ESPNet/test/eval_wsi_segmentation.py \
+            --staining=OPT_PAS \
+            --target_list=/opt/ESPNet/example/opt_pas_test_list.txt \
+            --merged_detection_result_csv=%s/OPT_PAS_GlomusMergedList_test1.csv \
+            %s--wsi_dir=/opt/ESPNet/example/data/02_PAS \
+            --output_file=%s/seg_data_pred/seg_data_output.tsv \
+            --segmentation_pred_json_dir=%s/seg_data_pred \
+            --window_size=2400 \
+            --output_dir=%s/seg_data_pred""" % (out, extra, out, out, out)))
+        assert a.output_file.endswith("seg_data_output.tsv") and a.window_size == 2400 and a.staining == "OPT_PAS"
+        assert (a.seg_gt_json_dir is not None) == bool(extra)
+    d = composite.build_parser().parse_args(["--staining", "OPT_PAS", "--merged_detection_result_csv", "m", "--target_list", "t",
+                                             "--wsi_dir", "w", "--segmentation_pred_json_dir", "j", "--start", "3", "--end", "9",
+                                             "--iou_threshold", "0.5"])
+    assert (d.iou_threshold, d.start, d.end, d.output_file, d.output_dir, d.window_size, d.classes, d.no_save) == \
+        (0.5, 3, 9, "./output/seg_data_pred/seg_data_output.tsv", "./output/seg_data_pred", 2400, 5, False)   # :412-420
+    # the evaluation branch (all three ground-truth directories, :427) is refused with an explanation, not by argparse
+    rc = composite.main(["--staining", "OPT_PAS", "--merged_detection_result_csv", "m", "--target_list", "t", "--wsi_dir", "w",
+                         "--segmentation_pred_json_dir", "j", "--segmentation_gt_json_dir", "a", "--object_detection_gt_xml_dir", "b",
+                         "--segmentation_gt_png_dir", "c"])
+    assert rc == 2
+    # the reference's default device (--gpu_id -1 = CPU, VisualizeResults_iou.py:252-255,302) is refused likewise: this build
+    # has no CPU product path
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".pth") as f:
+        assert segment.main(["--rgb_data_dir", "d", "--weights", f.name, "--mean", "1", "2", "3", "--std", "1", "2", "3"]) == 2
