@@ -47,6 +47,9 @@ def build_parser():
     p.add_argument('--overlay', action='store_true')
     p.add_argument('--classes', default=5, type=int)
     p.add_argument('--batch', default=32, type=int, help='tiles per GPU pass (additive flag)')
+    p.add_argument('--workers', default=None, type=int,
+                   help='host threads that decode the next batch and encode / write the previous one while a batch is on the GPU '
+                        '(additive flag; default: the CPUs of this process, at most 16; 0 = the serial loop)')
     p.add_argument('--imageData', default='orig', choices=['orig', 'classmap', 'none'],
                    help="what the JSON's imageData holds (additive flag): 'orig' = the original crop as the reference stores it "
                         "(VisualizeResults_iou.py:179), 'classmap' = the class map (the variant commented out at :178, which is "
@@ -131,74 +134,149 @@ def img_arr_to_b64(arr):
     return base64.b64encode(f.getvalue()).decode('utf-8')
 
 
-def evaluate(args, engine, rgb_list, label_list, rank=0, world=1, dist=None):
-    """evaluateModel (:84-241) over this rank's range; the summary files are written by rank 0 for all ranks."""
+def _load_batch(names, label_names):
+    """decode stage (worker thread): the crops as cv2.imread gives them (:103) and the label images (:191-192)"""
+    from PIL import Image
+    images = [imageops.imread_bgr(n) for n in names]
+    labels = [None if ln is None else np.asarray(Image.open(ln)) for ln in label_names]
+    return images, labels
+
+
+def _emit_crop(args, img_name, label_name, img, cmap, net_map, lab, lab_r):
+    """Everything the loop body writes for ONE crop after the forward (:131-231): overlay / original images, the counts row,
+    the class map, the labelme JSON, with a label the per-image accuracy row and the combined image.  Host work only -- PNG /
+    JPEG encoding, contour tracing, base64 -- and no state shared with other crops, so it runs on a worker thread while the
+    GPU is busy with the next batch.  Returns what the summary files need: (pixel row, accuracy row | None, (patient, label
+    values) | None, confusion matrix | None)."""
     from PIL import Image
     from .contours import labelme_dict
+    patient = os.path.basename(os.path.dirname(img_name))
+    name = os.path.basename(img_name)
+    stem = name.rsplit(".", 1)[0]
+    odir = os.path.join(args.savedir, patient)
+    os.makedirs(odir, exist_ok=True)
+    overlayed = None
+    if args.colored or label_name is not None:
+        colour = imageops.colourise(cmap)                                                  # :139-143
+        overlayed = imageops.add_weighted(img, 0.4, colour, 0.6)
+        if args.overlay:
+            imageops.imwrite_bgr(os.path.join(odir, stem + "_overlay.jpg"), overlayed)    # :145-148
+            imageops.imwrite_bgr(os.path.join(odir, stem + "_org.png"), img)
+    counts = [int(np.count_nonzero(cmap == c)) for c in range(5)]                         # :151-155
+    row_pixel = "{},{},{},{},{},{},{}\n".format(patient, name.replace(args.img_extn, 'png'), *counts)
+    out_map = imageops.relabel_city(cmap) if args.cityFormat else cmap                     # :158-159
+    # The class map is always written beside the JSON (additive: the WSI compositor takes it from there); what the
+    # JSON's imageData holds follows --imageData (the reference: the ORIGINAL crop, :179, although
+    # eval_wsi_segmentation.py decodes it as a class map -- SURVEY quirks).
+    Image.fromarray(out_map).save(os.path.join(odir, stem + "_classmap.png"))
+    body = labelme_dict(out_map, name, stem + "_classmap.png")                             # :161-177
+    body["imageData"] = (img_arr_to_b64(img) if args.imageData == 'orig' else
+                         img_arr_to_b64(np.ascontiguousarray(out_map, dtype=np.uint8)) if args.imageData == 'classmap' else None)
+    with open(os.path.join(odir, name.replace(args.img_extn, 'json')), 'w') as f:
+        json.dump(body, f, indent=4)
+    if label_name is None:
+        return row_pixel, None, None, None
+    # the reference scores at network resolution (:195-203): the label is nearest-resized to the network size (lab_r, made on
+    # the GPU by the caller) and compared with img_out.max(1)[1] itself, NOT with the map that went to crop size and back
+    hist = confusion(net_map.ravel(), lab_r.ravel(), args.classes)
+    uniq = np.unique(lab_r)
+    _, _, per_iu, _ = metric_right(hist)
+    union = hist.sum(1) + hist.sum(0) - np.diag(hist)
+    miou_each = np.nanmean(np.diag(hist)[uniq] / union[uniq])                               # :208-209
+    flags = [1 if (uniq == c).any() else 0 for c in range(1, 5)]
+    row_acc = "{}/{},{},{},{},{},{},{},{},{},{},{}\n".format(
+        patient, name.replace(args.img_extn, 'png'), *flags, *per_iu[:5], miou_each)
+    # original | ground truth overlay | prediction overlay (:215-231)
+    gt_colour = imageops.colourise(np.minimum(lab, len(imageops.PALETTE) - 1).astype(np.uint8))
+    combined = np.concatenate([img, imageops.add_weighted(img, 0.4, gt_colour, 0.6), overlayed], axis=1)
+    cdir = os.path.join(args.savedir, "combined_images", patient)
+    os.makedirs(cdir, exist_ok=True)
+    imageops.imwrite_bgr(os.path.join(cdir, name.replace(args.img_extn, 'png')), combined)
+    return row_pixel, row_acc, (patient, uniq.tolist()), hist
+
+
+def default_workers():
+    """host threads of the decode-ahead / write-behind pool: the CPUs this process may run on (its rank's share of the node,
+    launch.place_rank), at most 16"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def evaluate(args, engine, rgb_list, label_list, rank=0, world=1, dist=None):
+    """evaluateModel (:84-241) over this rank's range; the summary files are written by rank 0 for all ranks.
+
+    The reference decodes, infers and writes one crop at a time on one thread (:100-231).  Here the GPU takes a batch per
+    pass, and with args.workers > 0 the host work either side of it overlaps with it: a thread pool decodes the PNGs of batch
+    k+1 and encodes / traces / writes the outputs of batch k-1 while batch k is on the GPU (PIL's codecs and the contour
+    tracer release the interpreter lock).  Rows and matrices are collected in list order, so every output file is byte for
+    byte what the serial path (workers == 0: the same two functions, called inline) writes."""
+    from concurrent.futures import ThreadPoolExecutor
     from .shard import gather_rows, reduce_sum_to_all
     mean = [float(v) for v in args.mean]
     std = [float(v) for v in args.std]
     os.makedirs(args.savedir, exist_ok=True)
     total_hist = np.zeros((args.classes, args.classes), dtype=np.int64)
     rows_pixel, rows_acc, seen = [], [], []
-    for s in range(0, len(rgb_list), args.batch):
-        names = rgb_list[s:s + args.batch]
-        images = [imageops.imread_bgr(n) for n in names]
-        masks, net_maps = segment_images(engine, images, mean, std, args.inWidth, args.inHeight, args.batch, want_net_maps=True)
-        for img_name, label_name, img, cmap, net_map in zip(names, label_list[s:s + args.batch], images, masks, net_maps):
-            patient = os.path.basename(os.path.dirname(img_name))
-            name = os.path.basename(img_name)
-            stem = name.rsplit(".", 1)[0]
-            odir = os.path.join(args.savedir, patient)
-            os.makedirs(odir, exist_ok=True)
-            overlayed = None
-            if args.colored or label_name is not None:
-                colour = imageops.colourise(cmap)                                                  # :139-143
-                overlayed = imageops.add_weighted(img, 0.4, colour, 0.6)
-                if args.overlay:
-                    imageops.imwrite_bgr(os.path.join(odir, stem + "_overlay.jpg"), overlayed)    # :145-148
-                    imageops.imwrite_bgr(os.path.join(odir, stem + "_org.png"), img)
-            counts = [int(np.count_nonzero(cmap == c)) for c in range(5)]                         # :151-155
-            rows_pixel.append("{},{},{},{},{},{},{}\n".format(patient, name.replace(args.img_extn, 'png'), *counts))
-            out_map = imageops.relabel_city(cmap) if args.cityFormat else cmap                     # :158-159
-            # The class map is always written beside the JSON (additive: the WSI compositor takes it from there); what the
-            # JSON's imageData holds follows --imageData (the reference: the ORIGINAL crop, :179, although
-            # eval_wsi_segmentation.py decodes it as a class map -- SURVEY quirks).
-            Image.fromarray(out_map).save(os.path.join(odir, stem + "_classmap.png"))
-            body = labelme_dict(out_map, name, stem + "_classmap.png")                             # :161-177
-            body["imageData"] = (img_arr_to_b64(img) if args.imageData == 'orig' else
-                                 img_arr_to_b64(np.ascontiguousarray(out_map, dtype=np.uint8)) if args.imageData == 'classmap' else None)
-            with open(os.path.join(odir, name.replace(args.img_extn, 'json')), 'w') as f:
-                json.dump(body, f, indent=4)
-            if label_name is not None:
+    workers = max(0, int(getattr(args, "workers", 0) or 0))
+    pool = ThreadPoolExecutor(max_workers=workers) if workers > 0 else None
+
+    def run(fn, *a):
+        if pool is None:
+            class Done:          # the serial path: the call happens here and now
+                def __init__(self, v): self.v = v
+                def result(self): return self.v
+            return Done(fn(*a))
+        return pool.submit(fn, *a)
+
+    def collect(futs):
+        nonlocal total_hist
+        for f in futs:
+            rp, ra, sn, hist = f.result()
+            rows_pixel.append(rp)
+            if ra is not None:
+                rows_acc.append(ra)
+                seen.append(sn)
+                total_hist += hist
+
+    starts = list(range(0, len(rgb_list), args.batch))
+    try:
+        nxt = run(_load_batch, rgb_list[starts[0]:starts[0] + args.batch], label_list[starts[0]:starts[0] + args.batch]) if starts else None
+        pending = []          # emit futures of the batches behind the one on the GPU, oldest first
+        for bi, s in enumerate(starts):
+            names, label_names = rgb_list[s:s + args.batch], label_list[s:s + args.batch]
+            images, labels = nxt.result()
+            if bi + 1 < len(starts):      # decode ahead
+                s2 = starts[bi + 1]
+                nxt = run(_load_batch, rgb_list[s2:s2 + args.batch], label_list[s2:s2 + args.batch])
+            masks, net_maps = segment_images(engine, images, mean, std, args.inWidth, args.inHeight, args.batch, want_net_maps=True)
+            labs_r = []
+            for img_name, label_name, img, lab in zip(names, label_names, images, labels):
+                if label_name is None:
+                    labs_r.append(None)
+                    continue
                 assert os.path.basename(img_name) == os.path.basename(label_name)
-                lab = np.asarray(Image.open(label_name))
                 assert lab.shape[:2] == img.shape[:2]
-                # the reference scores at network resolution (:195-203): the label is nearest-resized to the network size and
-                # compared with img_out.max(1)[1] itself, NOT with the map that went to crop size and back
                 if lab.shape[:2] == (args.inHeight, args.inWidth):
-                    lab_r = lab
+                    labs_r.append(lab)
                 else:
                     import torch
                     from .engine import mask_resize_nearest
-                    lab_r = mask_resize_nearest(torch.from_numpy(np.array(lab, dtype=np.uint8)).to(engine.device),
-                                                args.inHeight, args.inWidth).cpu().numpy()      # :195 cv2.resize INTER_NEAREST
-                hist = confusion(net_map.ravel(), lab_r.ravel(), args.classes)
-                total_hist += hist
-                uniq = np.unique(lab_r)
-                seen.append((patient, uniq.tolist()))
-                _, _, per_iu, _ = metric_right(hist)
-                union = hist.sum(1) + hist.sum(0) - np.diag(hist)
-                miou_each = np.nanmean(np.diag(hist)[uniq] / union[uniq])                           # :208-209
-                flags = [1 if (uniq == c).any() else 0 for c in range(1, 5)]
-                rows_acc.append("{}/{},{},{},{},{},{},{},{},{},{},{}\n".format(
-                    patient, name.replace(args.img_extn, 'png'), *flags, *per_iu[:5], miou_each))
-                # original | ground truth overlay | prediction overlay (:215-231)
-                gt_colour = imageops.colourise(np.minimum(lab, len(imageops.PALETTE) - 1).astype(np.uint8))
-                combined = np.concatenate([img, imageops.add_weighted(img, 0.4, gt_colour, 0.6), overlayed], axis=1)
-                cdir = os.path.join(args.savedir, "combined_images", patient)
-                os.makedirs(cdir, exist_ok=True)
-                imageops.imwrite_bgr(os.path.join(cdir, name.replace(args.img_extn, 'png')), combined)
+                    labs_r.append(mask_resize_nearest(torch.from_numpy(np.array(lab, dtype=np.uint8)).to(engine.device),
+                                                      args.inHeight, args.inWidth).cpu().numpy())      # :195 cv2.resize INTER_NEAREST
+            futs = [run(_emit_crop, args, n_, l_, im, np.array(cm), np.array(nm) if nm is not None else None, lb, lr)
+                    for n_, l_, im, cm, nm, lb, lr in zip(names, label_names, images, masks, net_maps, labels, labs_r)]
+            # (np.array: the maps are views of the pipeline's pinned output buffer, which the next call may reuse)
+            pending.append(futs)
+            if len(pending) > 2:          # write behind: at most two batches of outputs in flight
+                collect(pending.pop(0))
+        for futs in pending:
+            collect(futs)
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
     # ---- one set of summary files (:91-98,232-241): rows in the order of the sorted list, one confusion matrix
     rows_pixel = gather_rows(rows_pixel, rank, world, dist)
     rows_acc = gather_rows(rows_acc, rank, world, dist)
@@ -259,6 +337,8 @@ def main(argv=None):
     from .engine import EspnetEngine
     from .shard import init_from_env
     rank, world, local, dist = init_from_env()
+    if args.workers is None:          # (after init_from_env: a rank's CPU share is set there)
+        args.workers = default_workers()
     # one process per GPU: every rank on its own device (LOCAL_RANK); a single process keeps the reference's --gpu_id
     dev_id = args.gpu_id if world == 1 or os.environ.get("GLOMSEG_ONE_GPU") == "1" else local
     torch.cuda.set_device(dev_id)

@@ -805,3 +805,56 @@ def test_reference_readme_command_lines_parse():
     import tempfile
     with tempfile.NamedTemporaryFile(suffix=".pth") as f:
         assert segment.main(["--rgb_data_dir", "d", "--weights", f.name, "--mean", "1", "2", "3", "--std", "1", "2", "3"]) == 2
+
+
+def test_segment_cli_overlapped_host_work_writes_the_same_bytes(tmp_path, monkeypatch):
+    """segment.evaluate with a decode-ahead / write-behind pool against its serial loop (--workers 0): every output file byte
+    for byte, rows in list order -- with labels (accuracy rows, combined images, the summed confusion matrix) and without.
+    The GPU pass is replaced by a deterministic stand-in: this is about the host pipeline around it."""
+    import filecmp
+    from PIL import Image
+    from glomeruli_segmentation_amd import segment
+    from glomeruli_segmentation_amd.synth import synth_tile
+
+    def fake_segment_images(engine, images, mean, std, width, height, batch, want_net_maps=False):
+        outs, nets = [], []
+        for im in images:
+            cm = (im[:, :, 0].astype(np.int32) // 52).astype(np.uint8) % 5
+            ys = (np.arange(height) * im.shape[0] // height)
+            xs = (np.arange(width) * im.shape[1] // width)
+            outs.append(cm)
+            nets.append(np.ascontiguousarray(cm[ys][:, xs]))
+        return (outs, nets) if want_net_maps else outs
+    monkeypatch.setattr(segment, "segment_images", fake_segment_images)
+    rng = np.random.default_rng(3)
+    rgb, lab = tmp_path / "rgb", tmp_path / "lab"
+    n = 23
+    for k in range(n):
+        patient = "P%d" % (k % 3)
+        (rgb / patient).mkdir(parents=True, exist_ok=True)
+        (lab / patient).mkdir(parents=True, exist_ok=True)
+        tile = synth_tile(k, 32, 64, blobs=3)
+        Image.fromarray(np.ascontiguousarray(tile[:, :, ::-1])).save(rgb / patient / ("xmin%d_ymin0_xmax9_ymax9.PNG" % k))
+        Image.fromarray(rng.integers(0, 5, (32, 64), dtype=np.uint8)).save(lab / patient / ("xmin%d_ymin0_xmax9_ymax9.PNG" % k))
+    trees = {}
+    for tag, workers, with_labels in (("serial_l", 0, True), ("pool_l", 5, True), ("serial", 0, False), ("pool", 3, False)):
+        out = tmp_path / tag
+        argv = ["--rgb_data_dir", str(rgb), "--savedir", str(out), "--weights", "unused", "--mean", "1", "2", "3", "--std", "1", "2", "3",
+                "--inWidth", "64", "--inHeight", "32", "--batch", "4", "--colored", "--overlay", "--cityFormat", "--workers", str(workers)]
+        if with_labels:
+            argv += ["--label_data_dir", str(lab)]
+        args = segment.build_parser().parse_args(argv)
+        rgb_list = sorted(__import__("glob").glob(str(rgb) + "/*/*.PNG"))
+        label_list = sorted(__import__("glob").glob(str(lab) + "/*/*.PNG")) if with_labels else [None] * n
+        segment.evaluate(args, None, rgb_list, label_list)
+        files = sorted(os.path.relpath(os.path.join(d, f), out) for d, _, fs in os.walk(out) for f in fs)
+        trees[tag] = (out, files)
+    for a, b in (("serial_l", "pool_l"), ("serial", "pool")):
+        (oa, fa), (ob, fb) = trees[a], trees[b]
+        assert fa == fb and len(fa) > 4 * n
+        for f in fa:
+            assert filecmp.cmp(os.path.join(oa, f), os.path.join(ob, f), shallow=False), f
+    rows = open(trees["pool_l"][0] / "summary_pixel.csv").read().splitlines()[1:]
+    assert [r.split(",")[1] for r in rows] == [os.path.basename(p).replace("PNG", "png") for p in rgb_list]      # list order
+    assert len(open(trees["pool_l"][0] / "summary_accuracy.csv").read().splitlines()) == n + 1
+    assert os.path.isfile(trees["pool_l"][0] / "overall_accuracy.txt")
