@@ -367,6 +367,10 @@ static gs_status check_paste(const gs_paste_target *p)
         return GS_OK;
     GS_REQUIRE(p->slide_map && p->map_h > 0 && p->map_w > 0 && p->ds > 0, "paste target: null map or bad size");
     GS_REQUIRE((p->sx_lut == nullptr) == (p->sy_lut == nullptr), "paste target: give both tables or neither");
+    // crops of one launch (or of the other stream) that overlap meet through a 32-bit compare-and-swap on the aligned word that
+    // holds the byte: the map must start on a 4-byte boundary and its allocation must cover whole words
+    GS_REQUIRE((reinterpret_cast<uintptr_t>(p->slide_map) & 3u) == 0,
+               "paste target: slide_map must be 4-byte aligned (and its allocation padded to a multiple of 4 bytes)");
     return GS_OK;
 }
 
@@ -478,12 +482,21 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
     };
     // three streams at three priorities, as in gs_espnet_segment_host (espnet.hip): HIP keeps a pool of hardware queues per
     // priority, so the upload stream and the two compute streams never share a queue whatever else the process has made
-    if (!p.h2d) {
+    if (!p.h2d || !p.compute[0] || !p.compute[1]) {   // all three or none: a partial set would run later calls on the NULL stream
         int lo = 0, hi = 0;
         fail(hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange");
-        fail(hipStreamCreateWithPriority(&p.h2d, hipStreamNonBlocking, hi), "hipStreamCreate");
-        fail(hipStreamCreateWithPriority(&p.compute[0], hipStreamNonBlocking, (lo + hi) / 2), "hipStreamCreate");
-        fail(hipStreamCreateWithPriority(&p.compute[1], hipStreamNonBlocking, lo), "hipStreamCreate");
+        hipStream_t *want[3] = {&p.h2d, &p.compute[0], &p.compute[1]};
+        const int prio[3] = {hi, (lo + hi) / 2, lo};
+        for (int k = 0; k < 3 && rc == GS_OK; ++k)
+            if (!*want[k])
+                fail(hipStreamCreateWithPriority(want[k], hipStreamNonBlocking, prio[k]), "hipStreamCreate");
+        if (rc != GS_OK) {
+            for (hipStream_t *w : want) {
+                if (*w) hipStreamDestroy(*w);
+                *w = nullptr;
+            }
+            return rc;
+        }
     }
     if (p.cap_in < need_in || p.cap_out < need_out || p.cap_net < npx * batch || p.cap_batch < batch) {
         fail(hipDeviceSynchronize(), "hipDeviceSynchronize");

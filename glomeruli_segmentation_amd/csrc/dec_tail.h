@@ -18,41 +18,10 @@
 #include <type_traits>
 
 #include "conv_mfma.h"
-#include "espnet_kernels.h"
+#include "dec_tail_args.h"
 
 namespace gs {
 
-struct DecTailArgs {
-    // concat buffer: planes in torch.cat order, zero halo of one row / one column (Model.py:375)
-    const float *in;
-    long long in_sn;
-    int in_sc, in_pitch, in_off;
-    unsigned in_img_bytes;
-    const float *wpack;   // [3 ty][6 plane groups][64 lanes] A operands | 16: BN scale, shift, alpha [3][5] | classifier.weight [5][5][2][2]
-    float *logits;        // [N][CLS][2*H1][2*W1] or null
-    unsigned char *mask;  // [N][2*H1][2*W1] or null
-    unsigned long long *hist;   // [N][CLS] or null (zeroed by the caller)
-    float *ff;            // optional: the CBR output (stage "conv") as a gs::Act
-    long long ff_sn;
-    int ff_sc, ff_pitch, ff_off;
-    // ensemble (BASELINE cfg 5, definition in DESIGN.md): prob [N][CLS][2*H1][2*W1] accumulates ens_w * softmax(logits) over the
-    // member models.  ens_mode 1: first member (store), 2: a middle member (add), 3: the last member (add, then argmax of the
-    // sum -> mask + counts; nothing is written back), 4: a single member (softmax -> argmax, prob untouched).  0: no ensemble.
-    float *prob;
-    int ens_mode;
-    float ens_w;
-    int N, H1, W1;
-    int xbase, nstrips;   // this launch covers strips of 16P-2 output columns starting at column xbase
-    int bands, R, k3;     // bands of R = 3*k3 + 2 output rows
-    int total_tasks;
-    // second task list of the same launch (NRUN2 > 0): the narrow rest of every row, one strip of NRUN2 column blocks per image
-    int xbase2, bands2, R2, k32, total_tasks2;
-    int grid_main;        // workgroups of the first list; the ones behind them take the second
-    int wu;               // waves of a workgroup that take tasks (all of them unless there are fewer tasks than wave slots)
-};
-
-constexpr int DT_A_FLOATS = 18 * 64;
-constexpr int DT_PACK_FLOATS = DT_A_FLOATS + 16 + 100;
 
 template <int N_>
 using IC = std::integral_constant<int, N_>;
@@ -524,7 +493,7 @@ static gs_status launch_dec_tail_p(DecTailArgs a, int num_cus, hipStream_t strea
 
 // Full-width strips (126 output columns, eight MFMA column blocks) and the narrow rest of the row, if any (512 = 4 x 126 + 8),
 // in ONE launch: the rest strips of 8 / NRUN2 images are packed into a task of the kernel's second task list.
-static inline gs_status launch_dec_tail(DecTailArgs a, int num_cus, hipStream_t stream)
+gs_status launch_dec_tail(DecTailArgs a, int num_cus, hipStream_t stream)
 {
     constexpr int XS = DecTailGeom<5, 8>::XS;
     const int full_strips = a.W1 / XS, rest = a.W1 - full_strips * XS;

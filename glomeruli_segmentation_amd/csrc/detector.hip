@@ -844,11 +844,19 @@ gs_status gs_detector_detect_host(gs_detector *h, const uint8_t *const *windows,
         }
         return e != hipSuccess;
     };
-    if (!d.pipe_h2d) {
+    if (!d.pipe_h2d || !d.pipe_compute) {   // both or neither: a partial pair would run later calls on the NULL stream
         int lo = 0, hi = 0;
         fail(hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange");
-        fail(hipStreamCreateWithPriority(&d.pipe_h2d, hipStreamNonBlocking, hi), "hipStreamCreate");
-        fail(hipStreamCreateWithPriority(&d.pipe_compute, hipStreamNonBlocking, lo), "hipStreamCreate");
+        if (rc == GS_OK && !d.pipe_h2d)
+            fail(hipStreamCreateWithPriority(&d.pipe_h2d, hipStreamNonBlocking, hi), "hipStreamCreate");
+        if (rc == GS_OK && !d.pipe_compute)
+            fail(hipStreamCreateWithPriority(&d.pipe_compute, hipStreamNonBlocking, lo), "hipStreamCreate");
+        if (rc != GS_OK) {
+            if (d.pipe_h2d) hipStreamDestroy(d.pipe_h2d);
+            if (d.pipe_compute) hipStreamDestroy(d.pipe_compute);
+            d.pipe_h2d = d.pipe_compute = nullptr;
+            return rc;
+        }
     }
     if (d.pipe_in_bytes < in_b * batch || d.pipe_batch < batch) {
         fail(hipDeviceSynchronize(), "hipDeviceSynchronize");

@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "conv_mfma.h"
-#include "dec_tail.h"
+#include "dec_tail_args.h"
 #include "espnet_kernels.h"
 #include "host_copy.h"
 

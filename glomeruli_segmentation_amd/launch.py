@@ -112,15 +112,15 @@ def _parse_cpulist(text):
     return cpus
 
 
-def gpu_numa_nodes(sysfs="/sys"):
-    """NUMA node of every GPU in KFD topology order (= HIP device order when HIP_VISIBLE_DEVICES does not permute it), from
-    sysfs alone -- no GPU call.  [] when the topology cannot be read; -1 for a GPU whose node is unknown."""
+def gpu_pci_addresses(sysfs="/sys"):
+    """PCI address "dddd:bb:dd.f" of every GPU in KFD topology order, from sysfs alone -- no GPU call.  [] when the topology
+    cannot be read."""
     root = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
     try:
         ids = sorted((int(d) for d in os.listdir(root) if d.isdigit()))
     except OSError:
         return []
-    nodes = []
+    out = []
     for i in ids:
         props = {}
         for line in (_read(os.path.join(root, str(i), "properties")) or "").splitlines():
@@ -133,13 +133,43 @@ def gpu_numa_nodes(sysfs="/sys"):
             loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
         except ValueError:
             continue
-        bdf = "%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 0x7)
+        out.append("%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 0x7))
+    return out
+
+
+def gpu_numa_nodes(sysfs="/sys"):
+    """NUMA node of every GPU in KFD topology order (= HIP device order when HIP_VISIBLE_DEVICES does not permute it; checked
+    after the device is initialised by check_device_order).  [] when the topology cannot be read; -1 for a GPU whose node is
+    unknown."""
+    nodes = []
+    for bdf in gpu_pci_addresses(sysfs):
         numa = _read(os.path.join(sysfs, "bus", "pci", "devices", bdf, "numa_node"))
         try:
             nodes.append(int(numa))
         except (TypeError, ValueError):
             nodes.append(-1)
     return nodes
+
+
+def check_device_order(local_rank, pci_domain, pci_bus, pci_device, sysfs="/sys", env=None):
+    """place_rank chose this rank's CPUs BEFORE the first GPU call, from the assumption that HIP device `local_rank` is the
+    local_rank-th visible GPU of the KFD topology.  Once the device is initialised its PCI address is known
+    (torch.cuda.get_device_properties(i).pci_domain_id / pci_bus_id / pci_device_id): compare.  Returns (ok, message); ok is
+    None when the topology cannot be read.  A mismatch costs speed (staging buffers on the far NUMA node), not correctness, so
+    callers log it and go on."""
+    env = os.environ if env is None else env
+    phys = gpu_pci_addresses(sysfs)
+    if not phys:
+        return None, "KFD topology unreadable: device order not checked"
+    vis = visible_gpu_indices(len(phys), env)
+    if local_rank >= len(vis):
+        return None, "local rank %d beyond the %d visible GPUs of the topology" % (local_rank, len(vis))
+    want = phys[vis[local_rank]]
+    have = "%04x:%02x:%02x" % (pci_domain, pci_bus, pci_device)
+    if want.rsplit(".", 1)[0] == have:
+        return True, "HIP device %d is %s, as the KFD topology order says" % (local_rank, have)
+    return False, ("HIP device %d is at PCI %s but the KFD topology order puts %s there: this rank's CPU placement (NUMA node) was "
+                   "chosen for the wrong GPU" % (local_rank, have, want))
 
 
 def visible_gpu_indices(n_physical, env=None):

@@ -17,7 +17,7 @@ import torch
 
 from . import detect, merge
 from .composite import SlideCompositor
-from .shard import rank_range
+from .shard import all_reduce_any, rank_range
 
 
 def segment_crops(engine, crops, mean, std, net_h, net_w, batch=32, paste=None, origins=None, want_masks=True):
@@ -61,6 +61,6 @@ def run_slide(engine, read_region, slide_w, slide_h, mpp_x, mpp_y, detector, mea
     if cnt is not None:
         counts += torch.from_numpy(cnt.sum(0)).to(dev)
     if dist is not None and world > 1:
-        dist.all_reduce(counts)
-        dist.all_reduce(comp.map, op=dist.ReduceOp.MAX)    # max-composite is associative: one collective
+        all_reduce_any(counts, dist)                       # (backend-aware: device tensors as they are under RCCL, via the host under gloo)
+        all_reduce_any(comp.map, dist, op=dist.ReduceOp.MAX)    # max-composite is associative: one collective
     return {"boxes": boxes, "masks": masks, "map": comp.map, "counts": counts, "plan": plan, "range": (lo, hi)}

@@ -54,7 +54,39 @@ def init_from_env(use_gpu=True):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+    if use_gpu and torch.cuda.is_available() and os.environ.get("GLOMSEG_ONE_GPU") != "1":
+        log_device_order(local)
     return rank, world, local, dist
+
+
+def log_device_order(local):
+    """after the device exists: is HIP device `local` the GPU place_rank pinned this rank's CPUs for?  (stderr; never fatal)"""
+    import sys
+    import torch
+    from .launch import check_device_order
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        ok, msg = check_device_order(local, pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception as e:      # an attribute this torch lacks, a device that went away: placement is a speed matter only
+        ok, msg = None, "device order not checked (%s)" % e
+    if ok is False:
+        print("WARNING rank placement: " + msg, file=sys.stderr)
+    return ok, msg
+
+
+def all_reduce_any(t, dist, op=None):
+    """dist.all_reduce of a tensor wherever it lives: as it is under "nccl" (RCCL takes device tensors, GPU to GPU over xGMI),
+    staged through the host under "gloo" (the CPU tests and the one-GPU rehearsal), which cannot take them.  In place."""
+    if dist is None:
+        return t
+    kw = {} if op is None else {"op": op}
+    if dist.get_backend() != "gloo" or not t.is_cuda:
+        dist.all_reduce(t, **kw)
+    else:
+        tc = t.cpu()
+        dist.all_reduce(tc, **kw)
+        t.copy_(tc)
+    return t
 
 
 def finish_ranks(dist):

@@ -135,7 +135,8 @@ typedef struct gs_crop_desc {
 } gs_crop_desc;
 
 typedef struct gs_paste_target {
-    uint8_t *slide_map;   /* device uint8 [map_h,map_w], accumulated into */
+    uint8_t *slide_map;   /* device uint8 [map_h,map_w], accumulated into.  4-byte aligned, allocation padded to a multiple of 4
+                           * bytes: overlapping crops meet through 32-bit compare-and-swap on the word around a byte */
     int32_t map_h, map_w, ds;
     const int *sx_lut;    /* device tables of gs_wsi_paste_max_lut, or both NULL for the regular grid */
     const int *sy_lut;

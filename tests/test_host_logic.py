@@ -858,3 +858,27 @@ def test_segment_cli_overlapped_host_work_writes_the_same_bytes(tmp_path, monkey
     assert [r.split(",")[1] for r in rows] == [os.path.basename(p).replace("PNG", "png") for p in rgb_list]      # list order
     assert len(open(trees["pool_l"][0] / "summary_accuracy.csv").read().splitlines()) == n + 1
     assert os.path.isfile(trees["pool_l"][0] / "overall_accuracy.txt")
+
+
+def test_device_order_check_against_the_kfd_topology(tmp_path):
+    """launch.check_device_order on a fake sysfs: the PCI address torch reports for HIP device i against the i-th visible GPU
+    of the KFD topology that place_rank assumed"""
+    from glomeruli_segmentation_amd import launch
+    sysfs = tmp_path / "sys"
+    nodes = sysfs / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    # node 0 = CPU; GPUs at 0000:05:00.0, 0000:15:00.0, 0000:85:00.0
+    for i, (simd, loc) in enumerate([(0, 0), (1024, 0x0500), (1024, 0x1500), (1024, 0x8500)]):
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("simd_count %d\nlocation_id %d\ndomain 0\n" % (simd, loc))
+    assert launch.gpu_pci_addresses(str(sysfs)) == ["0000:05:00.0", "0000:15:00.0", "0000:85:00.0"]
+    ok, msg = launch.check_device_order(1, 0, 0x15, 0, str(sysfs), {})
+    assert ok is True and "0000:15:00" in msg
+    ok, msg = launch.check_device_order(1, 0, 0x85, 0, str(sysfs), {})          # HIP enumerated another GPU second
+    assert ok is False and "0000:85:00" in msg and "0000:15:00.0" in msg
+    ok, _ = launch.check_device_order(0, 0, 0x85, 0, str(sysfs), {"HIP_VISIBLE_DEVICES": "2,0"})
+    assert ok is True                                                             # a visible-device list re-maps the ranks
+    ok, _ = launch.check_device_order(5, 0, 0x05, 0, str(sysfs), {})
+    assert ok is None
+    ok, _ = launch.check_device_order(0, 0, 0x05, 0, str(tmp_path / "nothing"), {})
+    assert ok is None

@@ -62,14 +62,12 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    def all_reduce(t, op=None):
-        kw = {} if op is None else {"op": op}
-        if backend == "nccl" or not t.is_cuda:
-            dist.all_reduce(t, **kw)
-        else:
-            tc = t.cpu()
-            dist.all_reduce(tc, **kw)
-            t.copy_(tc)
+    from glomeruli_segmentation_amd.shard import all_reduce_any, log_device_order
+    if world > 1 and os.environ.get("GS_BENCH_ONE_GPU") != "1" and not getattr(args, "dry_run", False):
+        log_device_order(local)      # is HIP device `local` the GPU place_rank pinned this rank's CPUs for? (stderr, never fatal)
+
+    def all_reduce(t, op=None):      # one helper owns the backend choice (device tensors as they are under RCCL, via the host under gloo)
+        all_reduce_any(t, dist, op)
 
     S, NW, NH, B = args.size, 1024, 512, 32
     folds = [1, 2, 3, 4, 5]

@@ -116,14 +116,12 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    from glomeruli_segmentation_amd.shard import all_reduce_any, log_device_order
+    if world > 1 and os.environ.get("GS_BENCH_ONE_GPU") != "1":
+        log_device_order(local)
+
     def all_reduce(t, op=None):
-        kw = {} if op is None else {"op": op}
-        if backend == "nccl" or not t.is_cuda:
-            dist.all_reduce(t, **kw)
-        else:
-            tc = t.cpu()
-            dist.all_reduce(tc, **kw)
-            t.copy_(tc)
+        all_reduce_any(t, dist, op)
 
     S, mpp = args.size, 0.2277
     example = np.load(os.path.join(REPO, "tests", "golden", "merge.npz"))["example_boxes"]
