@@ -484,12 +484,30 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         // issued: SQ_WAIT_ANY 57 % of wave cycles, MFMA pipe 42 % busy.)  The three horizontal taps
         // of a row are consecutive steps, so two of three B loads hit lines the wave has just pulled
         // into L1.
+        // (tap row, input-channel group) of row group g of chunk cw WITHIN its dilation.  g is a compile-time constant after
+        // unrolling; written as `(cw * G + g) / NSTEP` the compiler divided by NSTEP (mul_hi + shifts + fix-up: ~16 scalar
+        // instructions) for every row group of every chunk although the quotient is known per chunk: the fused level-3 ESP
+        // launch issued 394 scalar instructions per 78 matrix instructions, now 140 (worth 0.5-1 %: scalar issue overlaps the
+        // matrix pipe well -- profiles/r04_ab_bnload_isa.txt).  So the three shapes that occur are spelled out.
+        auto decode_rg = [&](int cw, int g, int &ty0, int &sidx) {
+            if constexpr (G % NSTEP == 0) {          // a chunk is whole tap rows (level 2: a whole dilation)
+                ty0 = cw * (G / NSTEP) + g / NSTEP;
+                sidx = g % NSTEP;
+            } else if constexpr (NSTEP % G == 0) {   // a tap row is whole chunks (stride-2 reduces, 1x1s)
+                constexpr int CPR = NSTEP / G;
+                ty0 = cw / CPR;
+                sidx = (cw - ty0 * CPR) * G + g;
+            } else {
+                const int rg = cw * G + g;
+                ty0 = rg / NSTEP;
+                sidx = rg - ty0 * NSTEP;
+            }
+        };
         // operands of chunk c (dilation c / CPD, row groups (c % CPD)*G ..) into ring slots 0..D-1
         auto fetch_b = [&](const __amdgpu_buffer_rsrc_t &rs, int sb, int c, int g, int tx, bool fl) {
             const int di = c / CPD;
-            const int rg = (c - di * CPD) * G + g;
-            const int ty0 = rg / NSTEP;
-            const int sidx = rg - ty0 * NSTEP;
+            int ty0, sidx;
+            decode_rg(c - di * CPD, g, ty0, sidx);
             const int ty = S2FLIP && fl ? TYN - 1 - ty0 : ty0;
             const int toff = TAPS == 9 ? ((ty - 1) * a.in_pitch + (tx - 1)) << di : TAPS == 3 ? (ty - 1) * a.in_pitch : 0;
             const int soff = sb + (toff + sidx * KL * a.in_sc) * 4;
@@ -509,9 +527,8 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                     float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + p * MT * STRIDE * 4, soff, IAUX));
         };
         auto fetch_pair = [&](const __amdgpu_buffer_rsrc_t &rs, int sb, int c, int g, bool fl) {
-            const int rg = c * G + g;
-            const int ty0 = rg / NSTEP;
-            const int sidx = rg - ty0 * NSTEP;
+            int ty0, sidx;
+            decode_rg(c, g, ty0, sidx);
             const int ty = S2FLIP && fl ? TYN - 1 - ty0 : ty0;
             const int soff = sb + ((ty - 1) * a.in_pitch - 1 + sidx * KL * a.in_sc) * 4;
 #pragma unroll
@@ -526,9 +543,8 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         };
         auto fetch_a = [&](int c, int g, int tx, bool fl) {
             const int di = c / CPD;
-            const int rg = (c - di * CPD) * G + g;
-            const int ty0 = rg / NSTEP;
-            const int sidx = rg - ty0 * NSTEP;
+            int ty0, sidx;
+            decode_rg(c - di * CPD, g, ty0, sidx);
             const int ty = S2FLIP && fl ? TYN - 1 - ty0 : ty0;
             const int tap = TAPS == 9 ? ty * 3 + tx : TAPS == 3 ? ty : 0;
             if (FLAGS & F_X_NOLDS) {
@@ -544,9 +560,8 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
 
         // F_BNLOAD: the three parameters of this lane's channel in row group g of chunk c (task row yy); one group ahead
         auto bnl_fetch = [&](int cc, int gg, int yy, bool ff, float &sc2, float &sh2, float &al2, bool &raw) {
-            const int rgc = cc * G + gg;
-            const int ty0c = rgc / NSTEP;
-            const int sidxc = rgc - ty0c * NSTEP;
+            int ty0c, sidxc;
+            decode_rg(cc, gg, ty0c, sidxc);
             const int tyc = S2FLIP && ff ? TYN - 1 - ty0c : ty0c;
             raw = sidxc >= a.bnl_s0 && sidxc < a.bnl_s1;                // (wave-uniform) the other groups have identity parameters
             const bool padrow = yy * STRIDE + tyc - 1 < 0 && raw;
