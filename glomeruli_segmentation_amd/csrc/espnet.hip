@@ -57,6 +57,11 @@ void set_error(const char *fmt, ...)
 #define CFG_L3_BR_P2R    32, 8,   26,  9,   1,     5,   28,   25,   2, 13   // shipped fused ESP form: a third of a dilation in flight
 // small batches (launches with fewer tasks than SIMDs): 32-pixel strips -- the same accumulation chain per pixel, four /
 // two times the tasks (forward_impl picks the shape per launch from the task count; tools/latency.py)
+#ifndef CFG_SMALL_AGL
+#define CFG_SMALL_AGL 1   // the small-batch level-3 forms take their weights from L2 through the operand ring (F_A_GLOBAL: no LDS staging
+                          // phase in front of a lone wave's task; one tile 0.492 -> 0.481 ms, 0.0358 -> 0.0347 ms per launch; at full batches
+                          // the same flag LOSES 3-8 %, CFG_AGL_L3)
+#endif
 #define CFG_L3_BR_P1R    32, 8,   26,  9,   1,     5,   28,   25,   1, 13
 #define CFG_L3_C1S_BNL_P1 32, 8,  132, 9,   2,     1,   25,   25,   1, L3C1S_BNL_G
 #define CFG_DEC_CONV     16, 8,   24,  9,   1,     1,   5,    5,    8, 3
@@ -800,7 +805,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         ConvArgs ca = conv_args(m->r3[rd3], wb + m->l3_0.br, m->cc[0], nullptr, n);
         if (m->l3_0.fused_next) {   // no residual here: the four-pixel vector mapping still fits with the second accumulator set
             if (small3)
-                return launch_conv_mfma<CFG_L3_BR_P1R, F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3 | SKIP_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+                return launch_conv_mfma<CFG_L3_BR_P1R, F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3 | SKIP_L3 | (CFG_SMALL_AGL ? F_A_GLOBAL : 0)>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
 #if CFG_L3_DOWN_P2
             if (ca.W % 2 == 0 && !no_vec())
                 return launch_conv_mfma<CFG_L3_BR_P2R, F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3 | F_VEC | SKIP_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
@@ -832,7 +837,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
 #endif
             if (fuse_next) {
                 if (small3)   // (one pixel per lane: a whole slot's residual fits in registers, requested a dilation ahead)
-                    return launch_conv_mfma<CFG_L3_BR_P1R, F_BNACT | F_RES | POL_L3_ESP | AGL_L3 | FUSE_L3 | SKIP_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+                    return launch_conv_mfma<CFG_L3_BR_P1R, F_BNACT | F_RES | POL_L3_ESP | AGL_L3 | FUSE_L3 | SKIP_L3 | (CFG_SMALL_AGL ? F_A_GLOBAL : 0)>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
 #if CFG_L3_FUSE_P4
                 // four pixels per lane with the residual through a half-slot register ring (round 2's first fused form)
                 if (ca.W % 4 == 0 && !no_vec())
@@ -847,7 +852,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
                 return launch_conv_mfma<CFG_L3_BR_P2F, F_BNACT | F_RES | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
             }
             if (small3)
-                return launch_conv_mfma<CFG_L3_BR_P1R, F_BNACT | F_RES | POL_L3_ESP | AGL_L3 | SKIP_L3>(ca, m->num_cus, s);
+                return launch_conv_mfma<CFG_L3_BR_P1R, F_BNACT | F_RES | POL_L3_ESP | AGL_L3 | SKIP_L3 | (CFG_SMALL_AGL ? F_A_GLOBAL : 0)>(ca, m->num_cus, s);
 #if CFG_L3_LAST_P2
             // the last (unfused) block in the half-row task shape of the fused ones, tap rows in the halo skipped
             if (ca.W % 2 == 0 && !no_vec())
