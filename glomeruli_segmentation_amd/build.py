@@ -31,7 +31,7 @@ def _stale(lib):
         return True
     t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in _sources() + HEADERS] + [os.path.abspath(__file__)]
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") or f.endswith(".inc")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

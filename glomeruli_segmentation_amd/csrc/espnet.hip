@@ -557,70 +557,21 @@ static ConvArgs conv_args(const Act &in, const float *wpack, const Act &out, con
 
 static inline unsigned blocks_for(long long items) { return (unsigned)((items + 255) / 256); }
 
+// Timing / stamp variants of the forward (GS_VARIANT: ablations, per-wave stamps, the kernels a round replaced) live in
+// espnet_diag.inc and exist in -DGS_DIAG builds only.  forward_impl offers them its launch sites through GS_DIAG_TRY; in the
+// product build that macro expands to nothing (its arguments are not even evaluated), so what follows is the shipped
+// schedule and nothing else.
 #ifdef GS_DIAG
-// Timing-only diagnostics (-DGS_DIAG builds, selected by GS_VARIANT; results are wrong by construction unless noted).
-// Level-2 branch kernel, per-chunk stamps of each wave's first task -> gpurun_out/stamps2.txt (tools/stamps2.py):
-//   140 full kernel   141 no epilogue   142 no residual   143 plain stores only
-static gs_status diag_l2_stamps(Model *m, ConvArgs ca, bool last, hipStream_t s)
-{
-    static unsigned long long *stamp2 = nullptr;
-    const size_t nst = 8192 * 64;
-    if (!stamp2)
-        GS_HIP(hipMalloc(reinterpret_cast<void **>(&stamp2), nst * 8));
-    GS_HIP(hipMemsetAsync(stamp2, 0, nst * 8, s));
-    ca.stamp = stamp2;
-    gs_status st = m->variant == 140   ? launch_conv_mfma<CFG_L2_BR, F_BNACT | F_RES | F_VEC | F_X_STAMP2>(ca, m->num_cus, s)
-                   : m->variant == 141 ? launch_conv_mfma<CFG_L2_BR, F_BNACT | F_RES | F_VEC | F_X_NOEPI | F_X_STAMP2>(ca, m->num_cus, s)
-                   : m->variant == 142 ? launch_conv_mfma<CFG_L2_BR, F_BNACT | F_VEC | F_X_STAMP2>(ca, m->num_cus, s)
-                                       : launch_conv_mfma<CFG_L2_BR, F_VEC | F_X_STAMP2>(ca, m->num_cus, s);
-    if (!last) {
-        std::vector<unsigned long long> h(nst);
-        GS_HIP(hipMemcpy(h.data(), stamp2, nst * 8, hipMemcpyDeviceToHost));
-        if (FILE *f = std::fopen("gpurun_out/stamps2.txt", "w")) {
-            for (size_t w = 0; w < 8192; ++w) {
-                if (!h[w * 64 + 2]) continue;
-                for (int k = 0; k < 54; ++k) std::fprintf(f, "%llu ", h[w * 64 + k]);
-                std::fprintf(f, "\n");
-            }
-            std::fclose(f);
-        }
-    }
-    return st;
-}
-// Level-3 branch kernel:
-//   101 no epilogue   102 no epilogue, no operand loads   103 ... and no LDS reads   104 no operand loads
-//   105 per-wave stamps -> gpurun_out/stamps.txt (tools/stamps.py; results correct)   109 stores but no residual
-static gs_status diag_l3_variants(Model *m, ConvArgs ca, int i, hipStream_t s)
-{
-    switch (m->variant) {
-    case 101: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | F_X_NOEPI>(ca, m->num_cus, s);
-    case 102: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI | F_X_NOLOAD>(ca, m->num_cus, s);
-    case 103: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_X_NOEPI | F_X_NOLOAD | F_X_NOLDS>(ca, m->num_cus, s);
-    case 104: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_X_NOLOAD>(ca, m->num_cus, s);
-    case 109: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_VEC>(ca, m->num_cus, s);
-    case 105: {
-        static unsigned long long *stamp = nullptr;
-        if (!stamp)
-            GS_HIP(hipMalloc(reinterpret_cast<void **>(&stamp), 4096 * 8 * 8));
-        GS_HIP(hipMemsetAsync(stamp, 0, 4096 * 8 * 8, s));
-        ca.stamp = stamp;
-        gs_status st = launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES | F_VEC | POL_L3_ESP | F_X_STAMP>(ca, m->num_cus, s);
-        if (i == m->q - 1) {
-            std::vector<unsigned long long> h(2048 * 8);
-            GS_HIP(hipMemcpy(h.data(), stamp, h.size() * 8, hipMemcpyDeviceToHost));
-            if (FILE *f = std::fopen("gpurun_out/stamps.txt", "w")) {
-                for (int w = 0; w < 2048; ++w) {
-                    for (int k = 0; k < 7; ++k) std::fprintf(f, "%llu ", h[w * 8 + k]);
-                    std::fprintf(f, "\n");
-                }
-                std::fclose(f);
-            }
-        }
-        return st;
-    }
-    default: return launch_conv_mfma<CFG_L3_BR, F_BNACT | F_RES>(ca, m->num_cus, s);
-    }
-}
+#include "espnet_diag.inc"
+#define GS_DIAG_TRY(call)     \
+    do {                      \
+        gs_status dst_;       \
+        if (call) return dst_; \
+    } while (0)
+#else
+#define GS_DIAG_TRY(call) \
+    do {                  \
+    } while (0)
 #endif
 
 template <int CLS>
@@ -677,10 +628,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
 
     // ---- level 2 (Model.py:351-357): DownSamplerB(19,64) then p ESP blocks
     L.run(K_L2_C1S, px2 * (19 * 9 * 12 * 2), [&] {
-#ifdef GS_DIAG
-        if (m->variant == 41)
-            return launch_conv_mfma<CFG_L2_C1S, 0>(conv_args(m->a0, wb + m->l2_0.c1, m->r2[0], nullptr, n), m->num_cus, s);
-#endif
+        GS_DIAG_TRY(diag_reduce_s2(m, 2, conv_args(m->a0, wb + m->l2_0.c1, m->r2[0], nullptr, n), s, dst_));
         return launch_conv_mfma<CFG_L2_C1S, F_S2PAIR | POL_L2_C1S | AGL_S2 | S2FLIP_L2>(conv_args(m->a0, wb + m->l2_0.c1, m->r2[0], nullptr, n), m->num_cus, s);
     });
     // b2 = BR(131) over cat([output1, output1_0, inp2]) (Model.py:359) never runs as a kernel: the last ESP block stores
@@ -721,13 +669,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         }
         if (fuse_b2) {
             ca = with_dual(ca, 64);
-#ifdef GS_DIAG
-            if (m->variant == 150) return launch_vec<F_BNACT | F_DUAL, CFG_L2_BR>(ca, m->num_cus, s);
-            // 151 (timing only, results wrong): the b2-normalised second store of the down-sampler dropped -- the ceiling of
-            // "let the consumers apply b2 on load" (profiles/README.md, round 3)
-            if (m->variant == 151 && m->l2_0.fused_next)
-                return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2, CFG_L2_BR_P4>(with_fused(conv_args(m->r2[rd2], wb + m->l2_0.br, m->bb[0], nullptr, n), m->r2[rd2 ^ 1], 12), m->num_cus, s);
-#endif
+            GS_DIAG_TRY(diag_l2_down(m, ca, with_fused(conv_args(m->r2[rd2], wb + m->l2_0.br, m->bb[0], nullptr, n), m->r2[rd2 ^ 1], 12), s, dst_));
             if (m->l2_0.fused_next)
                 return launch_vec<F_BNACT | F_DUAL | POL_L2_DOWN | AGL_L2 | FUSE_L2, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
             return launch_vec<F_BNACT | F_DUAL | POL_L2_DOWN | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
@@ -749,14 +691,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             });
         L.run(K_L2_ESP, px2 * (12 * 9 * 64 * 2) + (fuse_next ? px2 * (64 * 12 * 2) : 0), [&] {
             ConvArgs ca = conv_args(m->r2[rd2], wb + m->l2[i].br, m->bb[nxt], &m->bb[cur2], n);
-#ifdef GS_DIAG
-            if (m->variant >= 140 && m->variant <= 143)
-                return diag_l2_stamps(m, ca, last, s);
-            if (m->variant == 150) {
-                if (last) return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL, CFG_L2_BR>(with_dual(ca, 0), m->num_cus, s);
-                return launch_vec<F_BNACT | F_RES, CFG_L2_BR>(ca, m->num_cus, s);
-            }
-#endif
+            GS_DIAG_TRY(diag_l2_esp(m, ca, with_dual(ca, 0), last, s, dst_));
             if (last)
                 return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2, CFG_L2_BR_P4>(with_dual(ca, 0), m->num_cus, s);
             if (fuse_next)
@@ -785,10 +720,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     const bool small3 = (long long)n * H3 * cdiv(W3, 64) * 2 <= (long long)m->num_cus * 4 && !no_vec();
     int rd3 = 0;
     L.run(K_L3_C1S, px3 * (131 * 9 * 25 * 2), [&] {
-#ifdef GS_DIAG
-        if (m->variant == 41)
-            return launch_conv_mfma<CFG_L3_C1S, 0>(conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n), m->num_cus, s);
-#endif
+        GS_DIAG_TRY(diag_reduce_s2(m, 3, conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n), s, dst_));
         if (lazy_b2) {   // planes 64..127 of output1_cat hold output1_0 RAW: b2 is applied to the B operands on load
             ConvArgs ca = conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n);
             ca.bnl_s0 = 64 / 2;      // k-groups of two channels
@@ -831,10 +763,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             });
         L.run(K_L3_ESP, px3 * (25 * 9 * 128 * 2) + (fuse_next ? px3 * (128 * 25 * 2) : 0), [&] {
             ConvArgs ca = conv_args(m->r3[rd3], wb + m->l3[i].br, m->cc[nxt], &m->cc[cur3], n);
-#ifdef GS_DIAG
-            if (m->variant != 0 && m->variant != 30)
-                return diag_l3_variants(m, ca, i, s);
-#endif
+            GS_DIAG_TRY(diag_l3_esp(m, ca, i, s, dst_));
             if (fuse_next) {
                 if (small3)   // (one pixel per lane: a whole slot's residual fits in registers, requested a dilation ahead)
                     return launch_conv_mfma<CFG_L3_BR_P1R, F_BNACT | F_RES | POL_L3_ESP | AGL_L3 | FUSE_L3 | SKIP_L3 | (CFG_SMALL_AGL ? F_A_GLOBAL : 0)>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
@@ -920,32 +849,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     });
     set_stage("up_l2", m->ee, CLS);
     // ---- conv CBR(19+c,c,3) + classifier deconv + argmax + counts (Model.py:375-377, VisualizeResults_iou.py:128,151-155)
-#ifdef GS_DIAG
-    if (m->variant == 30 || (m->variant >= 171 && m->variant <= 173)) {   // the two-kernel tail this build replaced, for A/B timing
-        L.run(K_DEC_CONV, px1 * ((19 + CLS) * 9 * CLS * 2), [&] {
-            if (m->variant == 171)   // timing-only ablations
-                return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOEPI>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
-            if (m->variant == 172)
-                return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOLOAD>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
-            if (m->variant == 173)
-                return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | F_X_NOLOAD | F_X_NOEPI>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
-            return launch_conv_mfma<CFG_DEC_CONV_XM, F_BNACT | F_XMERGE | POL_DEC_CONV>(conv_args(m->a0c, wb + m->wconv_xm, m->ff, nullptr, n), m->num_cus, s);
-        });
-        set_stage("conv", m->ff, CLS);
-        L.run(K_DEC4, px1 * (CLS * CLS * 4 * 2), [&] {
-            Dec4Args a{};
-            a.f = view(m->ff);
-            a.wcl = wb + m->wclassifier;
-            a.logits = logits;
-            a.mask = mask;
-            a.hist = hist;
-            a.N = n;
-            hipLaunchKernelGGL(dec4_kernel<CLS>, dim3(blocks_for(((long long)H1 * W1 + DEC4_PX - 1) / DEC4_PX), n), dim3(256), 0, s, a);
-            return GS_OK;
-        });
-        return L.st;
-    }
-#endif
+    GS_DIAG_TRY((diag_two_kernel_tail<CLS>(m, L, n, H1, W1, logits, mask, hist, s, set_stage, dst_)));
     L.run(K_DEC_TAIL, px1 * ((19 + CLS) * 9 * CLS * 2) + px1 * (CLS * CLS * 4 * 2), [&] {
         DecTailArgs a{};
         a.in = m->a0c.base;
