@@ -63,21 +63,15 @@ constexpr bool kDtNoEpi = false;
 #ifndef DT_PRIO
 #define DT_PRIO 1      // second half of the workgroup's waves at s_setprio 1 (see below)
 #endif
-#ifndef DT_MERGE_REST
-#define DT_MERGE_REST 0   // 1: the rest strips as extra workgroups of the main launch (measured no better, profiles/README.md round 4); 0: a second launch
-#endif
 #ifndef DT_MAIN_WAVES
 #define DT_MAIN_WAVES 8
 #endif
-// NRUN2 > 0: the launch has a second task list, the narrow rest strips (NRUN2 column blocks per image, 8 / NRUN2 images side by
-// side), taken by extra workgroups behind the main grid (a block-uniform branch: the two bodies share no live registers).  As
-// a launch of its own that list took 0.034 ms of a 0.154 ms tail at batch 32 for 1.6 % of the pixels -- 512 two-row tasks that
-// cannot fill the chip; here its workgroups start on the CUs whose main workgroup retires first.
-template <int CLS, int NRUN, int NRUN2, int MODE, int WAVES>
+template <int CLS, int NRUN, int MODE, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs a)
 {
     constexpr bool DBG = MODE == 1, ENS = MODE == 2;
-    constexpr int P = DecTailGeom<CLS, NRUN>::P, NG = DecTailGeom<CLS, NRUN>::NG, TS = DecTailGeom<CLS, NRUN>::TS;
+    using DT = DecTailGeom<CLS, NRUN>;
+    constexpr int P = DT::P, NG = DT::NG, TS = DT::TS, XS = DT::XS, IMGS = DT::IMGS, CW = DT::CW, LPI = DT::LPI;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     if (tid < 128)
@@ -111,32 +105,30 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
     // epilogue the other one computes.
     if (DT_PRIO && wid >= WAVES / 2)
         __builtin_amdgcn_s_setprio(1);
-    // one task: band `task % bands` of column `task / bands` = (image group, strip) of a list with strips of NR column blocks
-    auto run_task = [&](auto nrun_, int task, int xbase, int nstrips, int bands, int R_, int k3_) __attribute__((always_inline)) {
-        constexpr int NR = decltype(nrun_)::value;
-        using DT = DecTailGeom<CLS, NR>;
-        constexpr int XS = DT::XS, IMGS = DT::IMGS, CW = DT::CW, LPI = DT::LPI;
-        const int col = task / bands;
-        const int b = task - col * bands;
-        const int ig = col / nstrips;
-        const int s = col - ig * nstrips;
+    // (a launch with fewer tasks than wave slots is spread over more CUs, a.wu waves of each taking tasks: launch_dec_tail_p)
+    const int nwaves = gridDim.x * a.wu;
+    for (int task = wid < a.wu ? blockIdx.x * a.wu + wid : a.total_tasks; task < a.total_tasks; task += nwaves) {
+        const int col = task / a.bands;
+        const int b = task - col * a.bands;
+        const int ig = col / a.nstrips;
+        const int s = col - ig * a.nstrips;
         const int n0 = ig * IMGS;                 // first image of the task
         const int nimg = min(IMGS, a.N - n0);     // (the last group may be short: its spare column blocks recompute the last image)
         // every band has exactly R = 3k+2 rows; the last one is shifted up to end at the image bottom and re-computes
         // (bit-identically re-stores) the rows it shares with its neighbour, which it must not count twice
-        const int rows = R_;
-        const int yb = b * R_;
+        const int rows = a.R;
+        const int yb = b * a.R;
         const int y0 = yb + rows <= a.H1 ? yb : a.H1 - rows;
-        const int x0 = xbase + XS * s;
+        const int x0 = a.xbase + XS * s;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.in + (long long)n0 * a.in_sn), 0, a.in_img_bytes * (unsigned)nimg, 0x00020000);
         const int sbase = (a.in_off + x0 - 1) * 4;   // column x0-1 of row 0; row -1 is the zero halo row
         // (uniform) offset of column block p: block p % NRUN of image n0 + p / NRUN -- added to the scalar offset of a load
-        int roffp[NR == 8 ? 1 : P];
-        if (NR < 8) {
+        int roffp[NRUN == 8 ? 1 : P];
+        if (NRUN < 8) {
 #pragma unroll
             for (int p = 0; p < P; ++p)
-                roffp[p] = min(p / NR, nimg - 1) * (int)a.in_img_bytes + (p % NR) * 64;
+                roffp[p] = min(p / NRUN, nimg - 1) * (int)a.in_img_bytes + (p % NRUN) * 64;
         }
         const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
             a.mask ? a.mask : reinterpret_cast<unsigned char *>(const_cast<float *>(a.in)), 0,
@@ -150,8 +142,8 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
             for (int p = 0; p < P; ++p)
                 bq[g][p] = kDtNoLoad ? __builtin_bit_cast(float, soff + p)
                                      : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                                     rs, NR == 8 ? voff + p * 64 : voff,
-                                                                     NR == 8 ? soff : soff + roffp[NR == 8 ? 0 : p], 0));
+                                                                     rs, NRUN == 8 ? voff + p * 64 : voff,
+                                                                     NRUN == 8 ? soff : soff + roffp[NRUN == 8 ? 0 : p], 0));
         };
         // one input row: every plane group feeds the vertical taps whose output row lies inside the band
         auto row_step = [&](auto ph_, auto v0_, auto v1_, auto v2_, auto more_, int inext) __attribute__((always_inline)) {
@@ -385,8 +377,8 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
         do_step(IC<0>{}, T, F, F, T, 0);
         do_step(IC<1>{}, T, T, F, T, 1);
         int t = 2;
-        if (k3_ > 0) {   // rows = 3*k3 + 2: the steady part is whole periods, no remainder
-            int it = k3_;
+        if (a.k3 > 0) {   // rows = 3*k3 + 2: the steady part is whole periods, no remainder
+            int it = a.k3;
             do {
                 do_step(IC<2>{}, T, T, T, T, t);
                 do_step(IC<0>{}, T, T, T, T, t + 1);
@@ -408,63 +400,36 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
                     atomicAdd(&a.hist[(long long)(n0 + gi) * CLS + k], (unsigned long long)c);
             }
         }
-    };
-    // (a launch with fewer tasks than wave slots is spread over more CUs, a.wu waves of each taking tasks: launch_dec_tail_p)
-    if (NRUN2 == 0 || (int)blockIdx.x < a.grid_main) {
-        const int nwaves = a.grid_main * a.wu;
-        for (int task = wid < a.wu ? blockIdx.x * a.wu + wid : a.total_tasks; task < a.total_tasks; task += nwaves)
-            run_task(IC<NRUN>{}, task, a.xbase, a.nstrips, a.bands, a.R, a.k3);
-    } else if constexpr (NRUN2 > 0) {
-        // the workgroups behind the main grid: they start as the first main workgroups retire and sweep the rest strips
-        const int nwaves = ((int)gridDim.x - a.grid_main) * WAVES;
-        for (int task = ((int)blockIdx.x - a.grid_main) * WAVES + wid; task < a.total_tasks2; task += nwaves)
-            run_task(IC<NRUN2>{}, task, a.xbase2, 1, a.bands2, a.R2, a.k32);
     }
 }
 
-// band height R = 3k+2 (the kernel's loop is whole periods of its three rolling accumulator sets): about one round of
-// tasks over the resident waves when the batch allows it -- a task is a serial sweep, so few long tasks would leave
-// most of the chip idle; operand re-reads are (R+2)/R
-static inline void dec_tail_bands(int H1, int cols, int slots, int &k3, int &R, int &bands)
-{
-    bands = slots / cols;
-    if (bands < 1) bands = 1;
-    k3 = (cdiv(H1, bands) - 2 + 2) / 3;   // smallest k with 3k+2 >= H1/bands
-    if (k3 < 0) k3 = 0;
-    while (k3 > 0 && 3 * k3 + 2 > H1) --k3;   // a band never exceeds the image (H1 >= 4; k3 == 0 gives two-row bands)
-    // a lane counts 8 pixels per band row into 12-bit fields: R <= 509 rows keeps an all-one-class band (4072) below 4096
-    if (k3 > 169) k3 = 169;
-    R = 3 * k3 + 2;
-    bands = cdiv(H1, R);
-}
-
-// One launch: strips of NRUN column blocks from column a.xbase on (a.nstrips per row) and, with NRUN2 > 0, the rest strip of
-// NRUN2 column blocks at column a.xbase2 as a second task list.
-template <int NRUN, int NRUN2, int WAVES>
+template <int NRUN, int WAVES>
 static gs_status launch_dec_tail_p(DecTailArgs a, int num_cus, hipStream_t stream)
 {
     using DT = DecTailGeom<5, NRUN>;
+    // band height R = 3k+2 (the kernel's loop is whole periods of its three rolling accumulator sets): about one round of
+    // tasks over the resident waves when the batch allows it -- a task is a serial sweep, so few long tasks would leave
+    // most of the chip idle; operand re-reads are (R+2)/R
     const int slots = num_cus * WAVES;
     const int cols = cdiv(a.N, DT::IMGS) * a.nstrips;
-    dec_tail_bands(a.H1, cols, slots, a.k3, a.R, a.bands);
+    int bands = slots / cols;
+    if (bands < 1) bands = 1;
+    int k3 = (cdiv(a.H1, bands) - 2 + 2) / 3;   // smallest k with 3k+2 >= H1/bands
+    if (k3 < 0) k3 = 0;
+    while (k3 > 0 && 3 * k3 + 2 > a.H1) --k3;   // a band never exceeds the image (H1 >= 4; k3 == 0 gives two-row bands)
+    // a lane counts 8 pixels per band row into 12-bit fields: R <= 509 rows keeps an all-one-class band (4072) below 4096
+    if (k3 > 169) k3 = 169;
+    a.k3 = k3;
+    a.R = 3 * k3 + 2;
+    a.bands = cdiv(a.H1, a.R);
     a.total_tasks = cols * a.bands;
-    a.total_tasks2 = 0;
-    if (NRUN2 > 0) {   // two-row tasks: the shortest there are, to ride on the waves that finish their main task first
-        a.k32 = 0;
-        a.R2 = 2;
-        a.bands2 = cdiv(a.H1, 2);
-        a.total_tasks2 = cdiv(a.N, DecTailGeom<5, NRUN2 ? NRUN2 : 1>::IMGS) * a.bands2;
-    }
-    if ((long long)a.N * 4 * a.H1 * a.W1 >= (1ll << 32) || (long long)DT::IMGS * a.in_img_bytes >= (1ll << 32) ||
-        (long long)(8 / (NRUN2 ? NRUN2 : 8)) * a.in_img_bytes >= (1ll << 32)) {
+    if ((long long)a.N * 4 * a.H1 * a.W1 >= (1ll << 32) || (long long)DT::IMGS * a.in_img_bytes >= (1ll << 32)) {
         set_error("dec_tail: batch of %d tiles of %dx%d exceeds the 32-bit offsets of the mask / input descriptors", a.N, 2 * a.H1, 2 * a.W1);
         return GS_ERR_UNSUPPORTED;
     }
     const size_t lds_bytes = (size_t)(128 + WAVES * 16 * DT::TS) * sizeof(float);
     const int mode = a.ens_mode ? 2 : a.logits ? 1 : 0;
-    auto kern = mode == 2   ? dec_tail_kernel<5, NRUN, NRUN2, 2, WAVES>
-                : mode == 1 ? dec_tail_kernel<5, NRUN, NRUN2, 1, WAVES>
-                            : dec_tail_kernel<5, NRUN, NRUN2, 0, WAVES>;
+    auto kern = mode == 2 ? dec_tail_kernel<5, NRUN, 2, WAVES> : mode == 1 ? dec_tail_kernel<5, NRUN, 1, WAVES> : dec_tail_kernel<5, NRUN, 0, WAVES>;
     static std::mutex mu;
     static std::map<int, bool> attr_done;
     int dev = 0;
@@ -479,55 +444,41 @@ static gs_status launch_dec_tail_p(DecTailArgs a, int num_cus, hipStream_t strea
     }
     int grid = num_cus;
     a.wu = WAVES;
-    if (a.total_tasks < grid * WAVES) {   // small batches: one wave per SIMD on as many CUs as there are tasks for
+    if (a.total_tasks < grid * WAVES) {   // small batches and the rest strips: one wave per SIMD on as many CUs as there are tasks for
         a.wu = cdiv(a.total_tasks, grid);
         grid = cdiv(a.total_tasks, a.wu);
     }
-    a.grid_main = grid;
-    if (NRUN2 > 0)
-        grid += std::min(cdiv(a.total_tasks2, WAVES), num_cus);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, a);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
 
-// Full-width strips (126 output columns, eight MFMA column blocks) and the narrow rest of the row, if any (512 = 4 x 126 + 8),
-// in ONE launch: the rest strips of 8 / NRUN2 images are packed into a task of the kernel's second task list.
+// Full-width strips (126 output columns, eight MFMA column blocks) in one launch; the narrow rest of the row, if any,
+// in a second one that packs the rest strips of 8 / NRUN images into every task.  (Round 4 built the rest strips into the main
+// launch twice -- as a second task list of the same waves, and as extra workgroups behind the main grid on a block-uniform
+// branch: 0.162-0.165 and 0.1618 ms against 0.1572 for the two launches (profiles/r04_ab_dec_tail_merge.txt).  Either way
+// the mask-only kernel, which holds 96 accumulators in 256 registers without a spill, started to spill (24-60 bytes), and its
+// 2048 main tasks end together, so the rest tasks find no idle tail to fill.  Not kept.)
 gs_status launch_dec_tail(DecTailArgs a, int num_cus, hipStream_t stream)
 {
     constexpr int XS = DecTailGeom<5, 8>::XS;
     const int full_strips = a.W1 / XS, rest = a.W1 - full_strips * XS;
-    const int nrun = rest > 0 ? cdiv(rest + 2, 16) : 0;
-#if !DT_MERGE_REST
     if (full_strips > 0) {
         a.xbase = 0;
         a.nstrips = full_strips;
-        gs_status st = launch_dec_tail_p<8, 0, DT_MAIN_WAVES>(a, num_cus, stream);
-        if (st != GS_OK || rest == 0) return st;
+        gs_status st = launch_dec_tail_p<8, DT_MAIN_WAVES>(a, num_cus, stream);
+        if (st != GS_OK) return st;
+    }
+    if (rest > 0) {
         a.xbase = full_strips * XS;
         a.nstrips = 1;
-        if (nrun <= 1) return launch_dec_tail_p<1, 0, 8>(a, num_cus, stream);
-        if (nrun <= 2) return launch_dec_tail_p<2, 0, 8>(a, num_cus, stream);
-        if (nrun <= 4) return launch_dec_tail_p<4, 0, 8>(a, num_cus, stream);
-        return launch_dec_tail_p<8, 0, 8>(a, num_cus, stream);
+        const int nrun = cdiv(rest + 2, 16);
+        if (nrun <= 1) return launch_dec_tail_p<1, 8>(a, num_cus, stream);
+        if (nrun <= 2) return launch_dec_tail_p<2, 8>(a, num_cus, stream);
+        if (nrun <= 4) return launch_dec_tail_p<4, 8>(a, num_cus, stream);
+        return launch_dec_tail_p<8, 8>(a, num_cus, stream);
     }
-#endif
-    if (full_strips > 0) {
-        a.xbase = 0;
-        a.nstrips = full_strips;
-        a.xbase2 = full_strips * XS;
-        // (two rest forms only -- every instantiation of this kernel costs seconds of build time: up to 14 columns eight images
-        // share a task, wider rests take a task per image)
-        if (nrun == 0) return launch_dec_tail_p<8, 0, DT_MAIN_WAVES>(a, num_cus, stream);
-        if (nrun <= 1) return launch_dec_tail_p<8, 1, DT_MAIN_WAVES>(a, num_cus, stream);
-        return launch_dec_tail_p<8, 8, DT_MAIN_WAVES>(a, num_cus, stream);
-    }
-    a.xbase = 0;      // a tile narrower than one full strip: the rest is all there is
-    a.nstrips = 1;
-    if (nrun <= 1) return launch_dec_tail_p<1, 0, 8>(a, num_cus, stream);
-    if (nrun <= 2) return launch_dec_tail_p<2, 0, 8>(a, num_cus, stream);
-    if (nrun <= 4) return launch_dec_tail_p<4, 0, 8>(a, num_cus, stream);
-    return launch_dec_tail_p<8, 0, 8>(a, num_cus, stream);
+    return GS_OK;
 }
 
 }  // namespace gs

@@ -29,9 +29,6 @@ struct DecTailArgs {
     int xbase, nstrips;   // this launch covers strips of 16P-2 output columns starting at column xbase
     int bands, R, k3;     // bands of R = 3*k3 + 2 output rows
     int total_tasks;
-    // second task list of the same launch (NRUN2 > 0): the narrow rest of every row, one strip of NRUN2 column blocks per image
-    int xbase2, bands2, R2, k32, total_tasks2;
-    int grid_main;        // workgroups of the first list; the ones behind them take the second
     int wu;               // waves of a workgroup that take tasks (all of them unless there are fewer tasks than wave slots)
 };
 
