@@ -265,6 +265,38 @@ def test_driver_end_to_end(torch_mod, tmp_path):
     assert (out / "PAS-001" / "xmin0_ymin0_xmax128_ymax64_overlay.jpg").exists()
 
 
+def test_driver_overlapped_equals_serial_on_the_gpu(torch_mod, tmp_path):
+    """the segment command line with its decode-ahead / write-behind thread pool against --workers 0, on the real GPU path: 13
+    crops of seven sizes (one of them network-sized), labels for all, three batches -- every file byte for byte"""
+    import filecmp
+    from PIL import Image
+    from conftest import GOLDEN
+    from glomeruli_segmentation_amd import segment
+    from glomeruli_segmentation_amd.synth import synth_tile
+    rng = np.random.default_rng(7)
+    sizes = [(512, 1024), (300, 420), (611, 587), (96, 1200), (777, 333), (256, 256), (431, 902)]
+    for k in range(13):
+        h, w = sizes[k % len(sizes)]
+        for sub, arr in (("org_image", synth_tile(60 + k, h, w, blobs=4)[:, :, ::-1]), ("label", rng.integers(0, 5, (h, w), dtype=np.uint8))):
+            d = tmp_path / sub / ("S%d" % (k % 2))
+            d.mkdir(parents=True, exist_ok=True)
+            Image.fromarray(np.ascontiguousarray(arr)).save(d / ("xmin%d_ymin0_xmax9_ymax9.PNG" % k))
+    outs = []
+    for workers in (0, 6):
+        out = tmp_path / ("results_w%d" % workers)
+        rc = segment.main(["--rgb_data_dir", str(tmp_path / "org_image"), "--label_data_dir", str(tmp_path / "label"), "--savedir", str(out),
+                           "--weights", os.path.join(GOLDEN, "weights_fold1.npz"), "--gpu_id", "0", "--mean", "204.60071", "170.19359",
+                           "199.57469", "--std", "20.61257", "42.92207", "28.401505", "--colored", "--overlay", "--cityFormat",
+                           "--batch", "5", "--workers", str(workers)])
+        assert rc == 0
+        outs.append(out)
+    files = sorted(os.path.relpath(os.path.join(d, f), outs[0]) for d, _, fs in os.walk(outs[0]) for f in fs)
+    assert len(files) == 13 * 5 + 4          # json, class map, original, overlay, combined image per crop + four summaries
+    assert files == sorted(os.path.relpath(os.path.join(d, f), outs[1]) for d, _, fs in os.walk(outs[1]) for f in fs)
+    for f in files:
+        assert filecmp.cmp(os.path.join(outs[0], f), os.path.join(outs[1], f), shallow=False), f
+
+
 def test_driver_loads_pth_and_scores_at_network_resolution(torch_mod, tmp_path):
     """the reference's weight format and scoring: `torch.save(state_dict)` -> `--weights x.pth`
     (VisualizeResults_iou.py:272,279), labels given, one crop NOT network-sized: the confusion matrix is built from

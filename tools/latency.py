@@ -64,7 +64,32 @@ def main():
         print("      " + "  ".join("%s=%.4f" % (k.replace("conv_", "").replace("_kernel", ""), v["avg_ms"]) for k, v in kern.items()),
               flush=True)
     eng.close()
-    out = {"what": "resident forward, uint8 1024x512 tiles -> masks + counts, one lane, fold-1 weights", "rows": rows}
+    # the LITERAL drop-in: the reference's loop body over the import-swapped module -- float32 [1,3,H,W] on
+    # the GPU in, `model(x)`, then VisualizeResults_iou.py:128 `img_out[0].max(0)[1].byte().cpu().data.numpy()`
+    import glomeruli_segmentation_amd.Model as Net
+    model = Net.ESPNet(5, 2, 8)
+    model.load_state_dict({k: torch.from_numpy(z[k]) for k in z.files})
+    model = model.to("cuda:0").eval()
+    x = torch.rand((1, 3, 512, 1024), dtype=torch.float32, device="cuda:0") * 0.02 - 0.01
+    for _ in range(5):
+        model(x)[0].max(0)[1].byte().cpu().data.numpy()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        cm = model(x)[0].max(0)[1].byte().cpu().data.numpy()
+    t_shim = (time.perf_counter() - t0) / 50
+    t0 = time.perf_counter()
+    for _ in range(50):
+        lg = model(x)
+    torch.cuda.synchronize()
+    t_fwd = (time.perf_counter() - t0) / 50
+    shim = {"ms_per_image_with_argmax_and_copy_out": round(t_shim * 1e3, 4), "images_per_s": round(1.0 / t_shim, 1),
+            "ms_per_forward_logits_only": round(t_fwd * 1e3, 4),
+            "what": "glomeruli_segmentation_amd.Model.ESPNet called as the reference's loop calls its model: batch 1, float32 NCHW in, "
+                    "fp32 logits out (10.5 MB written per tile), torch max + byte + copy to the host per image"}
+    print("shim batch 1: %.3f ms per image incl. argmax + .cpu() (%.0f images/s); forward alone %.3f ms" %
+          (shim["ms_per_image_with_argmax_and_copy_out"], shim["images_per_s"], shim["ms_per_forward_logits_only"]), flush=True)
+    out = {"what": "resident forward, uint8 1024x512 tiles -> masks + counts, one lane, fold-1 weights", "rows": rows,
+           "import_swap_batch1": shim}
     if args.out:
         with open(args.out, "w") as f:
             json.dump(out, f, indent=1)
