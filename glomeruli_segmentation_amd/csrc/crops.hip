@@ -594,9 +594,20 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
         // (gs_espnet_segment_host)
         if (masks) {
             if (s.out_direct) {
-                for (int j = 0; j < cnt && rc == GS_OK; ++j) {
-                    const size_t b = (size_t)s.descs[j].h * s.descs[j].w;
-                    fail(hipMemcpy2DAsync(masks[first + j], b, s.dout + s.descs[j].out_off, b, b, 1, hipMemcpyDeviceToHost, compute), "D2H copy");
+                // page-locked destinations laid out like the packed device buffer (every map at its 256-byte-aligned offset
+                // behind the batch's first one: what engine.segment_crops_host allocates) leave as ONE copy; 32 separate DMA
+                // commands per batch sat in the compute stream between two forwards
+                bool packed = true;
+                for (int j = 0; j < cnt; ++j)
+                    packed = packed && masks[first + j] == masks[first] + s.descs[j].out_off;
+                if (packed) {
+                    const size_t b = (size_t)s.descs[cnt - 1].out_off + (size_t)s.descs[cnt - 1].h * s.descs[cnt - 1].w;
+                    fail(hipMemcpy2DAsync(masks[first], b, s.dout, b, b, 1, hipMemcpyDeviceToHost, compute), "D2H copy");
+                } else {
+                    for (int j = 0; j < cnt && rc == GS_OK; ++j) {
+                        const size_t b = (size_t)s.descs[j].h * s.descs[j].w;
+                        fail(hipMemcpy2DAsync(masks[first + j], b, s.dout + s.descs[j].out_off, b, b, 1, hipMemcpyDeviceToHost, compute), "D2H copy");
+                    }
                 }
             } else {
                 fail(hipMemcpy2DAsync(s.hout, oo, s.dout, oo, oo, 1, hipMemcpyDeviceToHost, compute), "D2H copy");
