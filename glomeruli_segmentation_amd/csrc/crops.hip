@@ -428,11 +428,24 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
     if (st != GS_OK) return st;
     if (batch > MAXC) batch = MAXC;
     if (batch > n_crops) batch = n_crops;
-    // A short list -- one slide's crops (56 on the example slide, 7 per rank on eight GPUs) -- is cut into four batches of at
-    // least eight crops rather than one or two full ones: the first batch's upload and the last one's download are exposed,
-    // and since round 4 the forward keeps ~90 % of its full-batch rate down to 14-16 tiles (profiles/r04_latency.json)
-    if (n_crops < 4 * batch)
-        batch = std::max(std::min(batch, 8), (n_crops + 3) / 4);
+    // A short list -- one slide's crops (56 on the example slide, 7 per rank on eight GPUs) -- is cut into four batches rather
+    // than one or two full ones: the first batch's upload and the last one's download are exposed, and since round 4 the
+    // forward keeps ~90 % of its full-batch rate down to 14-16 tiles (profiles/r04_latency.json).  The first batch is the
+    // smallest (nothing overlaps its upload): 56 crops as 8 + 16 + 16 + 16 take 6.8-7.0 ms, as 4 x 14: 7.6, as 32 + 24: 10.1
+    int first_batch = batch;   // crops in the first batch (its upload is the pipeline's fill: nothing overlaps it)
+    if (n_crops < 4 * batch) {
+#ifndef CFG_SHORT_LIST_SPLIT
+#define CFG_SHORT_LIST_SPLIT 1   // 0: four equal batches; 1: a small first batch (a seventh of the list, at least 8), the rest in three
+#endif
+        const int floor8 = std::min(batch, 8);
+        if (CFG_SHORT_LIST_SPLIT && n_crops >= 32) {
+            first_batch = std::max(floor8, (n_crops + 6) / 7);
+            batch = std::max(floor8, (n_crops - first_batch + 2) / 3);
+        } else {
+            batch = std::max(floor8, (n_crops + 3) / 4);
+            first_batch = batch;
+        }
+    }
     for (int i = 0; i < n_crops; ++i) {
         GS_REQUIRE(crops[i] && (!masks || masks[i]), "crop %d: null pointer", i);
         GS_REQUIRE(heights[i] > 0 && widths[i] > 0 && (long long)heights[i] * widths[i] < (1ll << 29), "crop %d has a bad size %dx%d", i,
@@ -455,7 +468,7 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
     for (int first = 0; first < n_crops;) {
         size_t bi = 0, bo = 0;
         int i = first;
-        while (i < n_crops && i - first < batch) {
+        while (i < n_crops && i - first < (first == 0 ? first_batch : batch)) {
             const size_t ci = al((size_t)heights[i] * widths[i] * 3);
             if (i > first && bi + ci > kBatchBytes)
                 break;
@@ -576,7 +589,7 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
                 fail(hipMemcpyAsync(s.din + s.descs[j].in_off, crops[first + j], (size_t)s.descs[j].h * s.descs[j].w * 3, hipMemcpyHostToDevice,
                                     p.h2d), "H2D copy");
         } else {
-            parallel_jobs(cnt, 4, [&](int j) {
+            parallel_jobs(cnt, bi == 0 ? 8 : 4, [&](int j) {   // (the first batch's staging is exposed: more threads)
                 std::memcpy(s.hin + s.descs[j].in_off, crops[first + j], (size_t)s.descs[j].h * s.descs[j].w * 3);
             });
             fail(hipMemcpyAsync(s.din, s.hin, oi, hipMemcpyHostToDevice, p.h2d), "H2D copy");

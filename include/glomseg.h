@@ -166,7 +166,8 @@ gs_status gs_espnet_ensemble_segment_crops(gs_espnet *const *models, int n_model
  * between two compute streams (and two lanes when the handle has them), results come back by SDMA.  Outputs, each optional:
  * masks[i] (host uint8 [heights[i],widths[i]]), net_masks (host uint8 [n_crops,net_h,net_w]), hist (host uint64 [n_crops,5],
  * counts of the crop-size maps), paste + x1/y1 (level-0 origins).  n_models == 1 is the plain model; > 1 the ensemble.
- * A list shorter than four full batches is cut into four batches of at least eight crops (fill and drain are exposed).
+ * A list shorter than four full batches is cut into a small first batch (a seventh of the list, at least eight crops: its
+ * upload is the pipeline's fill) and three equal ones.
  * Page-locked masks[] that lie in ONE block, every map in a 256-byte-aligned slot right behind the previous one, are
  * written a batch per DMA -- the up to 255 padding bytes behind a map are written too (unspecified values); any other
  * layout is written map by map, exactly heights[i] * widths[i] bytes each.

@@ -24,7 +24,7 @@ crops = [np.ascontiguousarray(slide.read_region(b[0], b[1], b[2] - b[0], b[3] - 
 pinned = [torch.from_numpy(c).pin_memory() for c in crops]
 print("crops", len(crops), "MB in", sum(c.nbytes for c in crops) / 1e6)
 
-def t(f, n=5):
+def t(f, n=21):
     f(); torch.cuda.synchronize()
     ts = []
     for _ in range(n):
