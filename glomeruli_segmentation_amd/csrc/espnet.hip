@@ -575,8 +575,8 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     // ---- level 3 (Model.py:361-366)
     // Small batches: a half-row task per SIMD does not fill the chip below 8 tiles (64 rows x 2 strips x n tasks for 1024
     // SIMDs); with 32-pixel strips (one pixel per lane, the same accumulation chain per pixel: same bits) there are twice as
-    // many, each half as long.  Used while even those leave SIMDs without a task.
-    const bool small3 = (long long)n * H3 * cdiv(W3, 64) * 2 <= (long long)m->num_cus * 4 && !no_vec();
+    // many, each half as long.  Used up to one such task per wave slot (CFG_SMALL3_WAVES per CU: 8 tiles).
+    const bool small3 = (long long)n * H3 * cdiv(W3, 64) * 2 <= (long long)m->num_cus * CFG_SMALL3_WAVES && !no_vec();
     int rd3 = 0;
     L.run(K_L3_C1S, px3 * (131 * 9 * 25 * 2), [&] {
         GS_DIAG_TRY(diag_reduce_s2(m, 3, conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n), s, dst_));

@@ -41,6 +41,10 @@ namespace gs {
                           // phase in front of a lone wave's task; one tile 0.492 -> 0.481 ms, 0.0358 -> 0.0347 ms per launch; at full batches
                           // the same flag LOSES 3-8 %, CFG_AGL_L3)
 #endif
+#ifndef CFG_SMALL3_WAVES
+#define CFG_SMALL3_WAVES 8   // 32-pixel level-3 tasks while there are at most this many of them per CU (up to 8 tiles; with 4 -- one per
+                           // SIMD, up to 4 tiles -- eight tiles took 0.904 ms instead of 0.873, six 0.856 instead of 0.817)
+#endif
 #define CFG_L3_BR_P1R    32, 8,   26,  9,   1,     5,   28,   25,   1, 13
 #define CFG_L3_C1S_BNL_P1 32, 8,  132, 9,   2,     1,   25,   25,   1, L3C1S_BNL_G
 #define CFG_DEC_CONV     16, 8,   24,  9,   1,     1,   5,    5,    8, 3
