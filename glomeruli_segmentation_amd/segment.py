@@ -134,12 +134,20 @@ def img_arr_to_b64(arr):
     return base64.b64encode(f.getvalue()).decode('utf-8')
 
 
-def _load_batch(names, label_names):
-    """decode stage (worker thread): the crops as cv2.imread gives them (:103) and the label images (:191-192)"""
+def _load_crop(name, label_name):
+    """decode stage (worker thread), one crop: the image as cv2.imread gives it (:103) and its label image (:191-192)"""
     from PIL import Image
-    images = [imageops.imread_bgr(n) for n in names]
-    labels = [None if ln is None else np.asarray(Image.open(ln)) for ln in label_names]
-    return images, labels
+    return imageops.imread_bgr(name), (None if label_name is None else np.asarray(Image.open(label_name)))
+
+
+class _Done:
+    """a finished "future": the serial path (--workers 0) makes its calls on the spot"""
+
+    def __init__(self, value):
+        self.value = value
+
+    def result(self):
+        return self.value
 
 
 def _emit_crop(args, img_name, label_name, img, cmap, net_map, lab, lab_r):
@@ -224,12 +232,10 @@ def evaluate(args, engine, rgb_list, label_list, rank=0, world=1, dist=None):
     pool = ThreadPoolExecutor(max_workers=workers) if workers > 0 else None
 
     def run(fn, *a):
-        if pool is None:
-            class Done:          # the serial path: the call happens here and now
-                def __init__(self, v): self.v = v
-                def result(self): return self.v
-            return Done(fn(*a))
-        return pool.submit(fn, *a)
+        return _Done(fn(*a)) if pool is None else pool.submit(fn, *a)
+
+    def load(s):          # one future per crop: the decode of a batch spreads over the pool like its outputs do
+        return [run(_load_crop, n_, l_) for n_, l_ in zip(rgb_list[s:s + args.batch], label_list[s:s + args.batch])]
 
     def collect(futs):
         nonlocal total_hist
@@ -243,14 +249,14 @@ def evaluate(args, engine, rgb_list, label_list, rank=0, world=1, dist=None):
 
     starts = list(range(0, len(rgb_list), args.batch))
     try:
-        nxt = run(_load_batch, rgb_list[starts[0]:starts[0] + args.batch], label_list[starts[0]:starts[0] + args.batch]) if starts else None
+        nxt = load(starts[0]) if starts else None
         pending = []          # emit futures of the batches behind the one on the GPU, oldest first
         for bi, s in enumerate(starts):
             names, label_names = rgb_list[s:s + args.batch], label_list[s:s + args.batch]
-            images, labels = nxt.result()
+            loaded = [f.result() for f in nxt]
+            images, labels = [im for im, _ in loaded], [lb for _, lb in loaded]
             if bi + 1 < len(starts):      # decode ahead
-                s2 = starts[bi + 1]
-                nxt = run(_load_batch, rgb_list[s2:s2 + args.batch], label_list[s2:s2 + args.batch])
+                nxt = load(starts[bi + 1])
             masks, net_maps = segment_images(engine, images, mean, std, args.inWidth, args.inHeight, args.batch, want_net_maps=True)
             labs_r = []
             for img_name, label_name, img, lab in zip(names, label_names, images, labels):
