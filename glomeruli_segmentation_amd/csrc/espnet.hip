@@ -515,6 +515,8 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         a.nout3 = nout3;
         return a;
     };
+    // small batches: 32-pixel level-2 tasks while there are at most CFG_SMALL2_WAVES of them per CU (see small3 below)
+    const bool small2 = CFG_SMALL2_WAVES > 0 && (long long)n * H2 * cdiv(W2, 64) * 2 <= (long long)m->num_cus * CFG_SMALL2_WAVES && W2 % 2 == 0 && !no_vec();
     const bool fuse_b2 = m->p > 0;
     const bool lazy_b2 = fuse_b2 && CFG_LAZY_B2;
     m->b2_lazy = lazy_b2;
@@ -523,7 +525,11 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         ConvArgs ca = conv_args(m->r2[rd2], wb + m->l2_0.br, m->bb[0], nullptr, n);
         if (lazy_b2) {   // raw output only: b2 is applied by the consumers (level-3 stride-2 reduce, dec2)
             if (m->l2_0.fused_next)
+            {
+                if (small2)
+                    return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2, CFG_L2_BR_P2S>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
                 return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
+            }
             return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
         }
         if (fuse_b2) {
@@ -551,10 +557,16 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         L.run(K_L2_ESP, px2 * (12 * 9 * 64 * 2) + (fuse_next ? px2 * (64 * 12 * 2) : 0), [&] {
             ConvArgs ca = conv_args(m->r2[rd2], wb + m->l2[i].br, m->bb[nxt], &m->bb[cur2], n);
             GS_DIAG_TRY(diag_l2_esp(m, ca, with_dual(ca, 0), last, s, dst_));
-            if (last)
+            if (last) {
+                if (small2)
+                    return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2, CFG_L2_BR_P2S>(with_dual(ca, 0), m->num_cus, s);
                 return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2, CFG_L2_BR_P4>(with_dual(ca, 0), m->num_cus, s);
-            if (fuse_next)
+            }
+            if (fuse_next) {
+                if (small2)
+                    return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | FUSE_L2, CFG_L2_BR_P2S>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
                 return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | FUSE_L2, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
+            }
             return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
         });
         have_r2 = fuse_next;

@@ -41,6 +41,11 @@ namespace gs {
                           // phase in front of a lone wave's task; one tile 0.492 -> 0.481 ms, 0.0358 -> 0.0347 ms per launch; at full batches
                           // the same flag LOSES 3-8 %, CFG_AGL_L3)
 #endif
+#ifndef CFG_SMALL2_WAVES
+#define CFG_SMALL2_WAVES 4   // the same at level 2 (32-pixel strips, two pixels per lane; 0 = off): one tile 0.482 -> 0.471 ms; with 8 two
+                           // tiles took 0.511 instead of 0.505, so only while the tasks are at most one per SIMD
+#endif
+#define CFG_L2_BR_P2S     16, 8,   12,  9,   1,     5,   16,   12,   2, 9
 #ifndef CFG_SMALL3_WAVES
 #define CFG_SMALL3_WAVES 8   // 32-pixel level-3 tasks while there are at most this many of them per CU (up to 8 tiles; with 4 -- one per
                            // SIMD, up to 4 tiles -- eight tiles took 0.904 ms instead of 0.873, six 0.856 instead of 0.817)
