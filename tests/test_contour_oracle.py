@@ -90,6 +90,38 @@ def test_oracle_known_answers():
     assert orc.approx_poly_dp(poly, 0.5, closed=False)[:, 0].tolist() == [[0, 0], [5, 1], [10, 0]]
 
 
+def test_oracle_against_scipy_topology():
+    """the oracle itself against an implementation this repo did not write: scipy.ndimage says how many 8-connected components
+    and enclosed 4-connected background components an image has (= outer borders + hole borders) and which foreground pixels
+    touch background by a 4-neighbour (= the points CHAIN_APPROX_NONE visits); every traced border is a closed 8-connected
+    chain, and CHAIN_APPROX_SIMPLE keeps exactly the chain's direction changes"""
+    rng = np.random.default_rng(17)
+    s8, s4 = np.ones((3, 3), int), ndi.generate_binary_structure(2, 1)
+    for trial in range(10):
+        field = ndi.gaussian_filter(rng.standard_normal((90, 130)), 0.8 + trial)
+        img = (field > 0.03 / (1 + trial)).astype(np.uint8)
+        full = orc.find_contours(img, orc.CHAIN_APPROX_NONE)
+        simple = orc.find_contours(img, orc.CHAIN_APPROX_SIMPLE)
+        _, ncomp = ndi.label(img, structure=s8)
+        bl, nb = ndi.label(1 - img, structure=s4)
+        frame = (set(bl[0, :]) | set(bl[-1, :]) | set(bl[:, 0]) | set(bl[:, -1])) - {0}
+        assert len(full) == len(simple) == ncomp + (nb - len(frame)), trial
+        traced = set()
+        for c, cs in zip(full, simple):
+            pts = c[:, 0, :]
+            traced |= set(map(tuple, pts.tolist()))
+            if len(pts) > 1:
+                step = np.abs(np.diff(np.vstack([pts, pts[:1]]), axis=0)).max(axis=1)
+                assert (step == 1).all()                                   # a closed 8-connected chain
+            # SIMPLE = the points where the chain's direction changes (cyclically), in the same order
+            d = np.diff(np.vstack([pts[-1:], pts, pts[:1]]), axis=0)
+            turn = [tuple(p) for p, a, b in zip(pts.tolist(), d[:-1].tolist(), d[1:].tolist()) if a != b] if len(pts) > 1 else [tuple(pts[0])]
+            assert [tuple(p) for p in cs[:, 0, :].tolist()] == turn, trial
+        pad = np.pad(img, 1)
+        border = (img == 1) & ((pad[:-2, 1:-1] == 0) | (pad[2:, 1:-1] == 0) | (pad[1:-1, :-2] == 0) | (pad[1:-1, 2:] == 0))
+        assert traced == set(zip(*np.nonzero(border)[::-1])), trial
+
+
 def test_hole_start_on_a_diagonal_is_not_a_vertex():
     """the case that separated the product from OpenCV until round 4: a hole whose scan start pixel lies inside a straight
     SW-NE run of its border -- icvFetchContour starts with prev_s = s ^ 4, so that pixel is not written"""
