@@ -1197,8 +1197,8 @@ def test_ensemble_bench_one_slide_per_rank(torch_mod):
 # ------------------------------------------------------------------------------------------------------------------
 # the five stages chained through FILES, as the reference chains its scripts
 def test_cli_chain_detect_merge_crop_segment_composite(torch_mod, tmp_path):
-    """python -m ...detect (PNG branch, synthetic detector weights) -> python -m ...merge -> level-0 crops named as
-    make_seg_data.py:360 names them -> python -m ...segment -> python -m ...composite, every hand-over a file on disk;
+    """python -m ...detect (PNG branch, synthetic detector weights) -> python -m ...merge -> python -m ...crop (level-0 crops named
+    as make_seg_data.py:360 names them) -> python -m ...segment -> python -m ...composite, every hand-over a file on disk;
     the composited 1/8 map equals the oracle's window walk over the class maps the segment step wrote"""
     import json
     from PIL import Image
@@ -1234,12 +1234,24 @@ def test_cli_chain_detect_merge_crop_segment_composite(torch_mod, tmp_path):
     use = [b for b in boxes["H16-0001"] if 64 <= b[2] - b[0] <= 2000 and 64 <= b[3] - b[1] <= 2000 and b[0] >= 0 and b[1] >= 0
            and b[2] <= W and b[3] <= H][:6]
     assert len(use) >= 2
+    #    through the crop command line (make_seg_data.py's no-ground-truth branch) over a merged CSV cut down to those boxes
+    import csv
+    from glomeruli_segmentation_amd import crop
+    sub_csv = out / "detect" / "merged_subset.csv"
+    keep = set(tuple(b[:4]) for b in use)
+    with open(merged_csv) as f, open(sub_csv, "w") as g:
+        for line, row in zip(f.read().splitlines(), csv.reader(open(merged_csv))):
+            if tuple(int(v) for v in row[3:7]) in keep:
+                g.write(line + "\n")
+    assert crop.main(["--staining", "OPT_PAS", "--target_list", str(tl), "--merged_detection_result_csv", str(sub_csv), "--wsi_dir",
+                      str(data_dir / "02_PAS"), "--output_dir", str(out / "seg")]) == 0
     cdir = out / "seg" / "org_image" / "H16-0001"
-    cdir.mkdir(parents=True)
     for b in use:
-        ys = np.clip((b[1] + np.arange(b[3] - b[1])) // 8, 0, small.shape[0] - 1)
-        xs = np.clip((b[0] + np.arange(b[2] - b[0])) // 8, 0, small.shape[1] - 1)
-        Image.fromarray(small[ys][:, xs]).save(cdir / (merge.crop_name(b) + ".PNG"))
+        with Image.open(cdir / (merge.crop_name(b) + ".PNG")) as im:
+            assert im.size == (b[2] - b[0], b[3] - b[1]) and im.mode == "RGBA"
+            ys = np.clip((b[1] + np.arange(b[3] - b[1])) // 8, 0, small.shape[0] - 1)
+            xs = np.clip((b[0] + np.arange(b[2] - b[0])) // 8, 0, small.shape[1] - 1)
+            assert (np.asarray(im)[:, :, :3] == small[ys][:, xs]).all()
     # 4. segment
     mean, std = FOLD_MEAN_STD[1]
     assert segment.main(["--rgb_data_dir", str(out / "seg" / "org_image"), "--savedir", str(out / "seg" / "results"), "--weights",
