@@ -197,6 +197,7 @@ def generate_pred_wsi(args, out=sys.stdout):
     reference's 2400-px window walk into the 1/8 map, coloured and blended over the 1/8 slide image -> <slide>_pred.jpg
     (+ <slide>_pred_classmap.png, additive)."""
     import torch
+    from concurrent.futures import ThreadPoolExecutor
     from PIL import Image
     from . import detect, merge
     if args.window_size != WINDOW:
@@ -216,15 +217,20 @@ def generate_pred_wsi(args, out=sys.stdout):
         w, h = slide_size(args.wsi_dir, key, target_meta)
         comp = SlideCompositor(w, h, dev, reference_windows=True)
         used = 0
+        todo = []
         for b in boxes_of[key]:
             name = merge.crop_name(b)                                         # :268
             hits = [j for j in jsons if name in os.path.basename(j)]
             assert len(hits) <= 1
-            if not hits:
-                continue                                                      # :272-274: a crop without a segmentation
-            cm = relabel(np.ascontiguousarray(load_class_map(hits[0]), dtype=np.uint8))
+            if hits:                                                          # :272-274: a crop without a segmentation is skipped
+                todo.append((b, hits[0]))
+        # the class maps are decoded (JSON + PNG) by a few threads, then pasted in list order: max-compositing is order-free,
+        # the asserts are not
+        with ThreadPoolExecutor(max_workers=max(1, min(8, len(todo)))) as pool:
+            maps = list(pool.map(lambda t: relabel(np.ascontiguousarray(load_class_map(t[1]), dtype=np.uint8)), todo))
+        for (b, path), cm in zip(todo, maps):
             if cm.shape != (b[3] - b[1], b[2] - b[0]):
-                raise ValueError("%s: class map %s does not fit its box %s" % (hits[0], cm.shape, b[:4]))
+                raise ValueError("%s: class map %s does not fit its box %s" % (path, cm.shape, b[:4]))
             assert int(cm.max()) < args.classes                               # :314
             comp.paste(cm, b[0], b[1])
             used += 1
