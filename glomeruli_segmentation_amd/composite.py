@@ -245,7 +245,8 @@ def generate_pred_wsi(args, out=sys.stdout):
         blended = comp.overlay(small).cpu().numpy()
         results[key] = {"map": comp.map.cpu().numpy(), "crops": used}
         if not args.no_save:
-            Image.fromarray(np.ascontiguousarray(blended[:, :, ::-1])).save(os.path.join(args.output_dir, key + "_pred.jpg"))
+            Image.fromarray(np.ascontiguousarray(blended[:, :, ::-1])).save(os.path.join(args.output_dir, key + "_pred.jpg"),
+                                                                            quality=95)     # cv2.imwrite's default JPEG quality (:394)
             Image.fromarray(results[key]["map"]).save(os.path.join(args.output_dir, key + "_pred_classmap.png"))
         print("{}: {} crops composited on a {} x {} map".format(key, used, mw, mh), file=out)
     return results

@@ -3,6 +3,8 @@ reference's palette, addWeighted and the Cityscapes relabel.  The two ``cv2.resi
 (module/espnet/test/VisualizeResults_iou.py:114, :129) run on the GPU (gs_crop_preprocess / gs_mask_resize_nearest);
 their CPU restatement is test infrastructure and lives in oracle/image_oracle.py.
 """
+import os
+
 import numpy as np
 from PIL import Image
 
@@ -21,7 +23,18 @@ def imread_bgr(path):
 
 
 def imwrite_bgr(path, bgr):
-    Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(path)
+    """cv2.imwrite for 8-bit BGR images with cv2's default encoder parameters (the reference passes none, :147-150,231):
+    JPEG quality 95 (IMWRITE_JPEG_QUALITY; PIL's own default would be 75) and PNG compression level 1
+    (IMWRITE_PNG_COMPRESSION: "best speed"; PIL's default 6 takes three times as long for a few per cent of size).  The
+    encoders differ, so files are not byte-identical to cv2's; the pixels of a PNG are, a JPEG's within its quantisation."""
+    im = Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1]))
+    ext = os.path.splitext(path)[1].lower()
+    if ext in (".jpg", ".jpeg"):
+        im.save(path, quality=95)
+    elif ext == ".png":
+        im.save(path, compress_level=1)
+    else:
+        im.save(path)
 
 
 def colourise(class_map):
