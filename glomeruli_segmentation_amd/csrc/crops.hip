@@ -18,6 +18,12 @@
 #include "gs_internal.h"
 #include "host_copy.h"
 
+// gs_espnet_segment_crops_host, lists shorter than four full batches -- 0: four equal batches; 1: a small first batch (a seventh of the
+// list, at least 8 crops: its upload is the pipeline's fill), the rest in three (56 crops: 7.6 -> 6.9 ms, profiles/README.md round 4)
+#ifndef CFG_SHORT_LIST_SPLIT
+#define CFG_SHORT_LIST_SPLIT 1
+#endif
+
 namespace gs {
 
 constexpr int MAXC = GS_MAX_CROPS_PER_CALL;
@@ -434,9 +440,6 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
     // smallest (nothing overlaps its upload): 56 crops as 8 + 16 + 16 + 16 take 6.8-7.0 ms, as 4 x 14: 7.6, as 32 + 24: 10.1
     int first_batch = batch;   // crops in the first batch (its upload is the pipeline's fill: nothing overlaps it)
     if (n_crops < 4 * batch) {
-#ifndef CFG_SHORT_LIST_SPLIT
-#define CFG_SHORT_LIST_SPLIT 1   // 0: four equal batches; 1: a small first batch (a seventh of the list, at least 8), the rest in three
-#endif
         const int floor8 = std::min(batch, 8);
         if (CFG_SHORT_LIST_SPLIT && n_crops >= 32) {
             first_batch = std::max(floor8, (n_crops + 6) / 7);
