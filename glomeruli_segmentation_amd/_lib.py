@@ -15,7 +15,7 @@ if os.environ.get("GLOMSEG_LIB") and os.environ.get("GLOMSEG_EXPERIMENT") == "1"
 GS_OK = 0
 GS_IN_U8_BGR_NHWC = 0
 GS_IN_F32_NCHW = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 GS_BUILD_DIAG = 1
 MAX_CROPS_PER_CALL = 64
 
@@ -73,6 +73,8 @@ PROTOTYPES = {
     "gs_espnet_segment_crops_host": (_I, [ctypes.POINTER(_P), _I, ctypes.POINTER(_P), ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _FP, _FP,
                                      _I, _I, _I, ctypes.POINTER(_P), _P, _P, ctypes.POINTER(PasteTarget), ctypes.POINTER(_I),
                                      ctypes.POINTER(_I)]),
+    "gs_plan_crop_batches": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _I, ctypes.POINTER(_I), _I, ctypes.POINTER(_I)]),
+    "gs_host_block_is_pinned": (_I, [_P, ctypes.c_size_t]),
     "gs_espnet_ensemble_forward": (_I, [ctypes.POINTER(_P), _I, _P, _I, _I, _I, _FP, _FP, _P, _P, _P]),
     "gs_espnet_read_stage": (_I, [_P, ctypes.c_char_p, _I, _P, ctypes.c_size_t, ctypes.POINTER(_I * 3)]),
     "gs_espnet_block_forward": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),

@@ -16,7 +16,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libglomseg.so")
 SOURCES = ["espnet.hip", "dec_tail.hip", "crops.hip", "detect_ops.hip", "detector.hip", "contours.cpp"]
-HEADERS = ["gs_internal.h", "conv_mfma.h", "dec_tail.h", "dec_tail_args.h", "espnet_kernels.h", "crop_sample.h", "host_copy.h",
+HEADERS = ["gs_internal.h", "conv_mfma.h", "dec_tail.h", "dec_tail_args.h", "espnet_kernels.h", "crop_sample.h", "crop_plan.h", "host_copy.h", "host_jobs.h",
            os.path.join("..", "..", "include", "glomseg.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
          "-Wno-unused-value"]      # extra flags only through the command line (`-- ...` with --out): no environment knob

@@ -109,8 +109,9 @@ def output_org_files(args, out=sys.stdout):
         for b in boxes_of[key]:
             region = read_region(b[0], b[1], b[2] - b[0], b[3] - b[1])         # :358
             name = merge.crop_name(b)                                          # :360
-            if not args.no_save:
-                Image.fromarray(region).save(os.path.join(odir, name + '.PNG'), format="PNG")     # :361
+            # (written whatever --no_save says: the reference reads that flag in its ground-truth branch only, scan_files;
+            # output_org_files, make_seg_data.py:347-361, always saves)
+            Image.fromarray(region).save(os.path.join(odir, name + '.PNG'), format="PNG")     # :361
             names.append(name)
         written[key] = names
         print("{}: {} crops from {}".format(key, len(names), what), file=out)

@@ -14,15 +14,10 @@
 #include <memory>
 #include <vector>
 
+#include "crop_plan.h"
 #include "crop_sample.h"
 #include "gs_internal.h"
 #include "host_copy.h"
-
-// gs_espnet_segment_crops_host, lists shorter than four full batches -- 0: four equal batches; 1: a small first batch (a seventh of the
-// list, at least 8 crops: its upload is the pipeline's fill), the rest in three (56 crops: 7.6 -> 6.9 ms, profiles/README.md round 4)
-#ifndef CFG_SHORT_LIST_SPLIT
-#define CFG_SHORT_LIST_SPLIT 1
-#endif
 
 namespace gs {
 
@@ -293,6 +288,7 @@ static gs_status run_batch(gs_espnet *const *models, int n_models, int lane, con
 {
     CropPipe *pipe = pipe_of(models[0]);
     GS_REQUIRE(pipe, "out of host memory");
+    GS_REQUIRE(n >= 1 && n <= MAXC, "internal: a batch of %d crops does not fit the %d-entry descriptor table", n, MAXC);
     GS_REQUIRE(lane >= 0 && lane < 4, "lane %d out of range", lane);
     for (int k = 0; k < n_models; ++k)
         GS_REQUIRE(lane < espnet_lanes(models[k]), "model %d has no lane %d (gs_espnet_set_lanes)", k, lane);
@@ -419,6 +415,24 @@ gs_status gs_espnet_segment_crops(gs_espnet *h, int lane, const uint8_t *packed_
                      static_cast<hipStream_t>(hip_stream));
 }
 
+gs_status gs_plan_crop_batches(const int *heights, const int *widths, int n_crops, int batch, int *starts, int cap, int *n_batches)
+{
+    GS_REQUIRE(heights && widths && n_batches, "gs_plan_crop_batches: null argument");
+    GS_REQUIRE(n_crops > 0 && batch > 0, "gs_plan_crop_batches: n_crops and batch must be positive");
+    for (int i = 0; i < n_crops; ++i)
+        GS_REQUIRE(heights[i] > 0 && widths[i] > 0 && (long long)heights[i] * widths[i] < (1ll << 29), "crop %d has a bad size %dx%d", i,
+                   heights[i], widths[i]);
+    const CropBatchPlan plan = plan_crop_batches(heights, widths, n_crops, batch, MAXC);
+    *n_batches = (int)plan.starts.size() - 1;
+    if (!starts)
+        return GS_OK;
+    GS_REQUIRE(cap >= (int)plan.starts.size(), "gs_plan_crop_batches: %d entries needed, room for %d", (int)plan.starts.size(), cap);
+    std::copy(plan.starts.begin(), plan.starts.end(), starts);
+    return GS_OK;
+}
+
+int gs_host_block_is_pinned(const void *p, size_t bytes) { return p && host_block_is_pinned(p, bytes) ? 1 : 0; }
+
 gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, const uint8_t *const *crops, const int *heights,
                                        const int *widths, int n_crops, const float *means, const float *stds, int net_h, int net_w,
                                        int batch, uint8_t *const *masks, uint8_t *net_masks, unsigned long long *hist,
@@ -432,23 +446,6 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
     GS_REQUIRE(!paste || (x1 && y1), "a paste target needs the crops' level-0 origins");
     st = check_paste(paste);
     if (st != GS_OK) return st;
-    if (batch > MAXC) batch = MAXC;
-    if (batch > n_crops) batch = n_crops;
-    // A short list -- one slide's crops (56 on the example slide, 7 per rank on eight GPUs) -- is cut into four batches rather
-    // than one or two full ones: the first batch's upload and the last one's download are exposed, and since round 4 the
-    // forward keeps ~90 % of its full-batch rate down to 14-16 tiles (profiles/r04_latency.json).  The first batch is the
-    // smallest (nothing overlaps its upload): 56 crops as 8 + 16 + 16 + 16 take 6.8-7.0 ms, as 4 x 14: 7.6, as 32 + 24: 10.1
-    int first_batch = batch;   // crops in the first batch (its upload is the pipeline's fill: nothing overlaps it)
-    if (n_crops < 4 * batch) {
-        const int floor8 = std::min(batch, 8);
-        if (CFG_SHORT_LIST_SPLIT && n_crops >= 32) {
-            first_batch = std::max(floor8, (n_crops + 6) / 7);
-            batch = std::max(floor8, (n_crops - first_batch + 2) / 3);
-        } else {
-            batch = std::max(floor8, (n_crops + 3) / 4);
-            first_batch = batch;
-        }
-    }
     for (int i = 0; i < n_crops; ++i) {
         GS_REQUIRE(crops[i] && (!masks || masks[i]), "crop %d: null pointer", i);
         GS_REQUIRE(heights[i] > 0 && widths[i] > 0 && (long long)heights[i] * widths[i] < (1ll << 29), "crop %d has a bad size %dx%d", i,
@@ -460,33 +457,13 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
     int nl = 2;   // batches alternate between two lanes when every member has them
     for (int k = 0; k < n_models; ++k)
         if (espnet_lanes(models[k]) < 2) nl = 1;
-    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t npx = (size_t)net_h * net_w;
-    // batches: up to `batch` crops and up to kBatchBytes of crop pixels (one oversize crop still forms a batch of its own), so
-    // that a list of very large crops does not ask for gigabytes of pinned staging per slot
-    constexpr size_t kBatchBytes = 256u << 20;
-    std::vector<int> starts;
-    size_t need_in = 0, need_out = 0;
-    int max_cnt = 0;
-    for (int first = 0; first < n_crops;) {
-        size_t bi = 0, bo = 0;
-        int i = first;
-        while (i < n_crops && i - first < (first == 0 ? first_batch : batch)) {
-            const size_t ci = al((size_t)heights[i] * widths[i] * 3);
-            if (i > first && bi + ci > kBatchBytes)
-                break;
-            bi += ci;
-            bo += al((size_t)heights[i] * widths[i]);
-            ++i;
-        }
-        starts.push_back(first);
-        need_in = std::max(need_in, bi);
-        need_out = std::max(need_out, bo);
-        max_cnt = std::max(max_cnt, i - first);
-        first = i;
-    }
-    starts.push_back(n_crops);
-    batch = max_cnt;
+    // which crops go into which batch, and the staging a batch needs (csrc/crop_plan.h: host-only, sanitised on its own)
+    const CropBatchPlan plan = plan_crop_batches(heights, widths, n_crops, batch, MAXC);
+    const std::vector<int> &starts = plan.starts;
+    const size_t need_in = plan.need_in, need_out = plan.need_out;
+    batch = plan.max_count;
+    GS_REQUIRE(batch >= 1 && batch <= MAXC, "internal: planned a batch of %d crops", batch);
     constexpr int NSLOT = 4;
     gs_status rc = GS_OK;
     auto fail = [&](hipError_t e, const char *what) {
@@ -569,18 +546,10 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
         const int cnt = starts[bi + 1] - first;
         s.descs.assign(cnt, gs_crop_desc{});
         size_t oi = 0, oo = 0;
+        fill_crop_descs(heights, widths, x1, y1, first, cnt, s.descs.data(), &oi, &oo);
         bool in_direct = true;
         s.out_direct = masks != nullptr;
         for (int j = 0; j < cnt; ++j) {
-            gs_crop_desc &d = s.descs[j];
-            d.h = heights[first + j];
-            d.w = widths[first + j];
-            d.x1 = x1 ? x1[first + j] : 0;
-            d.y1 = y1 ? y1[first + j] : 0;
-            d.in_off = (int64_t)oi;
-            d.out_off = (int64_t)oo;
-            oi += al((size_t)d.h * d.w * 3);
-            oo += al((size_t)d.h * d.w);
             in_direct = in_direct && host_is_pinned(crops[first + j]);
             if (masks)
                 s.out_direct = s.out_direct && host_is_pinned(masks[first + j]);
@@ -616,8 +585,11 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
                 bool packed = true;
                 for (int j = 0; j < cnt; ++j)
                     packed = packed && masks[first + j] == masks[first] + s.descs[j].out_off;
+                const size_t b = (size_t)s.descs[cnt - 1].out_off + (size_t)s.descs[cnt - 1].h * s.descs[cnt - 1].w;
+                // ... and only when the whole range is ONE page-locked allocation: separately pinned buffers that happen to be
+                // neighbours in virtual memory are written map by map
+                packed = packed && host_block_is_pinned(masks[first], b);
                 if (packed) {
-                    const size_t b = (size_t)s.descs[cnt - 1].out_off + (size_t)s.descs[cnt - 1].h * s.descs[cnt - 1].w;
                     fail(hipMemcpy2DAsync(masks[first], b, s.dout, b, b, 1, hipMemcpyDeviceToHost, compute), "D2H copy");
                 } else {
                     for (int j = 0; j < cnt && rc == GS_OK; ++j) {

@@ -779,7 +779,7 @@ using namespace gs;
 extern "C" {
 
 const char *gs_last_error(void) { return g_err.c_str(); }
-int gs_abi_version(void) { return 3; }   // 2: lanes, block hook, detector, compositor LUT; 3: batched crop entries, detector host entry, build flags
+int gs_abi_version(void) { return 4; }   // 2: lanes, block hook, detector, compositor LUT; 3: batched crop entries, detector host entry, build flags; 4: any class count 2..20 (hist is [n,classes]), batch planner, pinned-block query, overlays from the crop pipeline
 int gs_build_flags(void)
 {
 #ifdef GS_DIAG

@@ -338,9 +338,9 @@ def main(argv=None, detector=None):
     try:
         split_all(args, detector, rank, world, dist)
     except BaseException:
+        abort_rank(dist)      # a rank that fails alone must not wait for its peers in a barrier -- and leaves before any GPU teardown that could block (shard.abort_rank)
         if own is not None:
             own.close()
-        abort_rank(dist)      # a rank that fails alone must not wait for its peers in a barrier (shard.abort_rank)
         raise
     if own is not None:
         own.close()

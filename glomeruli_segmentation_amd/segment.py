@@ -364,8 +364,11 @@ def main(argv=None):
     try:
         evaluate(args, engine, rgb_list, label_list, rank, world, dist)
     except BaseException:
-        engine.close()
-        abort_rank(dist)      # a rank that fails alone must not wait for its peers in a barrier (shard.abort_rank)
+        # a rank that fails alone must not wait for its peers in a barrier (shard.abort_rank) -- and it leaves FIRST: if the
+        # failure was a GPU fault or a hang, closing the engine (a device synchronise) could block for ever with the peers
+        # sitting in their gather; the process is exiting and the driver reclaims its device memory
+        abort_rank(dist)
+        engine.close()        # single process: tidy up, then let the exception (or a SystemExit's own code) through
         raise
     engine.close()
     finish_ranks(dist)

@@ -100,7 +100,9 @@ def abort_rank(dist):
     """Failure path (call from an `except` block): this rank failed ALONE -- an unreadable image, a shape assert, out of memory --
     while its peers sit in a gather / all-reduce.  A barrier here would be a collective the peers never reach: this rank would
     block until the backend's timeout instead of exiting, and launch.spawn_ranks, which ends the job when a child exits
-    non-zero, would never see it.  So: print the traceback, skip barrier and teardown, leave with status 1 -- at once, without
+    non-zero, would never see it.  So: print the traceback, skip barrier and teardown (callers close their GPU handles only AFTER
+    this returns, i.e. in single-process runs: a device synchronise after a GPU fault may never come back), leave with status 1
+    (a SystemExit's own non-zero code is kept) -- at once, without
     interpreter shutdown (a process-group destructor may itself wait for the peers).  With one rank the exception just
     propagates."""
     if dist is None:
@@ -108,10 +110,12 @@ def abort_rank(dist):
     import os
     import sys
     import traceback
+    exc = sys.exc_info()[1]
+    code = exc.code if isinstance(exc, SystemExit) and isinstance(exc.code, int) and exc.code != 0 else 1   # a SystemExit keeps its own code
     traceback.print_exc()
     sys.stdout.flush()
     sys.stderr.flush()
-    os._exit(1)
+    os._exit(code)
 
 
 def collective_device(dist, device=None):

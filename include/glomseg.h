@@ -177,6 +177,15 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
                                        int net_w, int batch, uint8_t *const *masks, uint8_t *net_masks,
                                        unsigned long long *hist, const gs_paste_target *paste, const int *x1, const int *y1);
 
+/* The batch plan gs_espnet_segment_crops_host follows, as a host-only function (no device work; csrc/crop_plan.h): batch b
+ * holds crops [starts[b], starts[b+1]); *n_batches batches, starts gets *n_batches + 1 entries (cap counts ints; with
+ * starts == NULL only the count is reported).  No batch holds more than min(batch, GS_MAX_CROPS_PER_CALL) crops or -- beyond its
+ * first crop -- more than 256 MiB of crop pixels. */
+gs_status gs_plan_crop_batches(const int *heights, const int *widths, int n_crops, int batch, int *starts, int cap, int *n_batches);
+/* 1 when the bytes [p, p + bytes) lie inside ONE page-locked host allocation (hipHostMalloc / hipHostRegister / torch
+ * pin_memory): such buffers are DMA'd in place by the host pipelines, and a batch's maps leave in one copy.  0 otherwise. */
+int gs_host_block_is_pinned(const void *p, size_t bytes);
+
 /* WSI compositor (the consumer of the gathered masks; eval_wsi_segmentation.py:243-316,215-241,359-394).
  * The slide-level class map lives at 1/ds of level 0 (ds = 8 in the reference): pixel (X,Y) holds the
  * class at level-0 pixel (ds*X, ds*Y), i.e. what INTER_NEAREST of a full 2400-px window yields (:229).

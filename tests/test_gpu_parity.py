@@ -1370,3 +1370,40 @@ print("ok")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-3000:]
+
+
+def test_batched_crop_entry_list_of_three_and_a_half_batches(torch_mod, engine1):
+    """230 small crops at batch 64 -- a list of 3.5 to 4 batches, where round 4's short-list split planned batches of 65-73
+    crops for a 64-entry descriptor table -- and 120 at batch 32: same maps and counts as small batches"""
+    from glomeruli_segmentation_amd import _lib
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD
+    mean, std = FOLD_MEAN_STD[1]
+    rng = np.random.default_rng(11)
+    sizes = [(int(rng.integers(20, 70)), int(rng.integers(20, 90))) for _ in range(230)]
+    crops = _crops(sizes, 900)
+    ref = engine1.segment_crops(crops, mean, std, 64, 128, batch=16)
+    for n, batch in ((230, 64), (120, 32), (227, 57)):
+        r = engine1.segment_crops(crops[:n], mean, std, 64, 128, batch=batch)
+        assert all(np.array_equal(a, b) for a, b in zip(ref["masks"][:n], r["masks"])), (n, batch)
+        assert np.array_equal(ref["counts"][:n], r["counts"]), (n, batch)
+    assert np.array_equal(ref["counts"].sum(1), [h * w for h, w in sizes])
+    # a batch larger than the descriptor table is refused by the device-resident entry, never run
+    with pytest.raises(_lib.GlomsegError):
+        d = _lib.CropDesc()
+        d.h, d.w = 8, 8
+        engine1.segment_crops_resident(torch_mod.zeros(8 * 8 * 3 * 65, dtype=torch_mod.uint8, device="cuda"), [d] * 65, mean, std, 64, 128)
+
+
+def test_pinned_block_query(torch_mod):
+    """gs_host_block_is_pinned: the test behind the one-DMA-per-batch download (a range is taken for one block only when it lies
+    inside ONE page-locked allocation)"""
+    import ctypes
+    torch = torch_mod
+    from glomeruli_segmentation_amd import _lib
+    lib = _lib.load()
+    a = torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True)
+    assert lib.gs_host_block_is_pinned(ctypes.c_void_p(a.data_ptr()), a.numel()) == 1
+    assert lib.gs_host_block_is_pinned(ctypes.c_void_p(a.data_ptr() + 4096), a.numel() - 4096) == 1
+    assert lib.gs_host_block_is_pinned(ctypes.c_void_p(a.data_ptr() + 4096), a.numel()) == 0      # runs past the allocation's end
+    b = np.zeros(1 << 20, dtype=np.uint8)
+    assert lib.gs_host_block_is_pinned(ctypes.c_void_p(b.ctypes.data), b.size) == 0               # pageable

@@ -926,3 +926,47 @@ def test_device_order_check_against_the_kfd_topology(tmp_path):
     assert ok is None
     ok, _ = launch.check_device_order(0, 0, 0x05, 0, str(tmp_path / "nothing"), {})
     assert ok is None
+
+
+def _plan(lib, heights, widths, batch):
+    import ctypes
+    n = len(heights)
+    hs = (ctypes.c_int * n)(*heights)
+    ws = (ctypes.c_int * n)(*widths)
+    nb = ctypes.c_int(0)
+    assert lib.gs_plan_crop_batches(hs, ws, n, batch, None, 0, ctypes.byref(nb)) == 0
+    starts = (ctypes.c_int * (nb.value + 1))()
+    assert lib.gs_plan_crop_batches(hs, ws, n, batch, starts, nb.value + 1, ctypes.byref(nb)) == 0
+    return list(starts)
+
+
+def test_crop_batch_plan_never_exceeds_the_callers_batch():
+    """the split arithmetic of gs_espnet_segment_crops_host for EVERY (batch, list length) up to four batches and beyond:
+    round 4's short-list split let lists of 3.5 to 4 batches grow past the caller's batch -- and past the 64-entry descriptor
+    table (a host stack overflow at e.g. batch 64, 230 crops)"""
+    from glomeruli_segmentation_amd import _lib
+    lib = _lib.load()
+    for batch in list(range(1, 65)) + [65, 100, 1000]:
+        cap = min(batch, _lib.MAX_CROPS_PER_CALL)
+        for n in list(range(1, 4 * cap + 10)) + [1000]:
+            starts = _plan(lib, [40] * n, [50] * n, batch)
+            sizes = np.diff(starts)
+            assert starts[0] == 0 and starts[-1] == n and (sizes > 0).all(), (batch, n, starts)
+            assert sizes.max() <= min(cap, n), (batch, n, sizes)
+            if n >= 4 * cap:                              # long lists: full batches
+                assert (sizes[:-1] == cap).all(), (batch, n, sizes)
+            elif n >= 32 or n > cap:                      # short lists are cut into (at least) four
+                assert len(sizes) >= min(4, -(-n // 8)), (batch, n, sizes)
+    # the cases the review named
+    assert max(np.diff(_plan(lib, [30] * 230, [30] * 230, 64))) <= 64
+    assert max(np.diff(_plan(lib, [30] * 120, [30] * 120, 32))) <= 32
+    assert max(np.diff(_plan(lib, [30] * 227, [30] * 227, 57))) <= 57
+    # the shape round 4 measured is kept where it fits: 56 crops at batch 32 -> 8 + 16 + 16 + 16
+    assert list(np.diff(_plan(lib, [30] * 56, [30] * 56, 32))) == [8, 16, 16, 16]
+    # byte cap: 4000 x 7000 crops (84 MB of pixels each) go three to a batch, one oversize crop alone
+    assert list(np.diff(_plan(lib, [4000] * 7, [7000] * 7, 32))) == [3, 3, 1]
+    assert list(np.diff(_plan(lib, [12000, 10, 10], [12000, 10, 10], 32))) == [1, 2]
+    import ctypes
+    nb = ctypes.c_int(0)
+    assert lib.gs_plan_crop_batches((ctypes.c_int * 1)(0), (ctypes.c_int * 1)(5), 1, 4, None, 0, ctypes.byref(nb)) != 0   # bad size
+    assert lib.gs_host_block_is_pinned(None, 10) == 0

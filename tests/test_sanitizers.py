@@ -79,3 +79,29 @@ def test_contours_under_asan_ubsan(tmp_path):
     assert res.returncode == 0, (res.returncode, res.stderr[-3000:])
     assert "AddressSanitizer" not in res.stderr and "runtime error" not in res.stderr, res.stderr[-3000:]
     assert "points kept" in res.stdout
+
+
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_crop_pipeline_host_side_under_sanitizers(tmp_path, san):
+    """the host code of gs_espnet_segment_crops_host that has no GPU in it -- the batch planner and packed-slot layout
+    (csrc/crop_plan.h) and the threaded staging copies (csrc/host_jobs.h) -- replayed by tests/helpers/host_side_driver.cpp on
+    1 000 random crop lists (lengths 0, 1, 7, 8, 63, 64, 65, ... and a list with 4000 x 7000 crops) under
+    AddressSanitizer + UndefinedBehaviorSanitizer and under ThreadSanitizer"""
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not available")
+    exe = tmp_path / "host_side_driver"
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=" + san, "-fno-sanitize-recover=all",
+           "-I" + os.path.join(REPO, "glomeruli_segmentation_amd", "csrc"),
+           os.path.join(REPO, "tests", "helpers", "host_side_driver.cpp"), "-o", str(exe)]
+    built = subprocess.run(cmd, capture_output=True, text=True)
+    if built.returncode != 0 and "sanitize" in built.stderr and ("cannot find" in built.stderr or "unrecognized" in built.stderr):
+        pytest.skip("sanitizer runtime not available: " + built.stderr[-300:])
+    assert built.returncode == 0, built.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:exitcode=77", UBSAN_OPTIONS="halt_on_error=1:exitcode=78",
+               TSAN_OPTIONS="halt_on_error=1:exitcode=79")
+    res = subprocess.run([str(exe), "1000"], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.returncode, res.stdout[-500:], res.stderr[-3000:])
+    assert "host side ok: 1" in res.stdout
+    for word in ("AddressSanitizer", "ThreadSanitizer", "runtime error"):
+        assert word not in res.stderr, res.stderr[-3000:]
