@@ -73,13 +73,15 @@ __global__ void __launch_bounds__(256) crops_prep_kernel(const CropTable t, cons
 // Nearest resize of every network-resolution mask back to its crop's size, four consecutive bytes of the flat crop map per
 // thread (one 32-bit store), and the per-class counts of the crop-size map: packed per-lane counters (12 bits per class, at
 // most 4 added per iteration and the grid is sized for <= 512 iterations), a butterfly add over the wave, one LDS atomic per
-// class per wave, one global atomic per class per workgroup.
+// class per wave, one global atomic per class per workgroup.  NW = 64-bit counter words per lane, five classes each (1 for the
+// five-class networks, up to 4 for GS_MAX_CLASSES = 20); hist is [n][classes].
+template <int NW>
 __global__ void __launch_bounds__(256)
-crops_back_kernel(const CropTable t, const unsigned char *net, int net_h, int net_w, unsigned char *out, unsigned long long *hist)
+crops_back_kernel(const CropTable t, const unsigned char *net, int net_h, int net_w, unsigned char *out, unsigned long long *hist, int classes)
 {
-    __shared__ unsigned lh[5];
+    __shared__ unsigned lh[5 * NW];
     const int i = blockIdx.y;
-    if (threadIdx.x < 5)
+    if (threadIdx.x < 5 * NW)
         lh[threadIdx.x] = 0;
     __syncthreads();
     const int h = t.d[i].h, w = t.d[i].w;
@@ -87,7 +89,10 @@ crops_back_kernel(const CropTable t, const unsigned char *net, int net_h, int ne
     const unsigned char *src = net + (long long)i * net_h * net_w;
     unsigned char *dst = out ? out + t.d[i].out_off : nullptr;
     const double ifx = cv_inv_scale(w, net_w), ify = cv_inv_scale(h, net_h);
-    unsigned long long counts = 0;
+    unsigned long long counts[NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q)
+        counts[q] = 0;
     for (long long base = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; base < hw; base += (long long)gridDim.x * 1024) {
         int oy = (int)(base / w), ox = (int)(base - (long long)oy * w);
         unsigned packed = 0;
@@ -97,7 +102,15 @@ crops_back_kernel(const CropTable t, const unsigned char *net, int net_h, int ne
             if (base + k < hw) {
                 const unsigned v = src[(long long)sy * net_w + nearest_src(ox, ifx, net_w)];
                 packed |= v << (8 * k);
-                counts += 1ull << (12 * (v < 5 ? v : 0));
+                const unsigned vc = v < (unsigned)classes ? v : 0;   // (a value no class map holds counts as background)
+                if (NW == 1) {
+                    counts[0] += 1ull << (12 * vc);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NW; ++q)
+                        if (vc / 5 == (unsigned)q)
+                            counts[q] += 1ull << (12 * (vc % 5));
+                }
             }
             if (++ox == w) {   // the four bytes may run over a row end
                 ox = 0;
@@ -115,8 +128,8 @@ crops_back_kernel(const CropTable t, const unsigned char *net, int net_h, int ne
     }
     if (hist) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            int c = (int)((counts >> (12 * k)) & 0xfffull);
+        for (int k = 0; k < 5 * NW; ++k) {
+            int c = (int)((counts[k / 5] >> (12 * (k % 5))) & 0xfffull);
 #pragma unroll
             for (int sh = 32; sh >= 1; sh >>= 1)
                 c += __shfl_xor(c, sh, 64);
@@ -124,8 +137,8 @@ crops_back_kernel(const CropTable t, const unsigned char *net, int net_h, int ne
                 atomicAdd(&lh[k], (unsigned)c);
         }
         __syncthreads();
-        if (threadIdx.x < 5 && lh[threadIdx.x])
-            atomicAdd(&hist[(long long)i * 5 + threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+        if ((int)threadIdx.x < classes && lh[threadIdx.x])
+            atomicAdd(&hist[(long long)i * classes + threadIdx.x], (unsigned long long)lh[threadIdx.x]);
     }
 }
 
@@ -184,7 +197,7 @@ struct CropPipe {
         size_t f32_bytes = 0;
         unsigned char *net = nullptr;   // network-resolution masks when the caller keeps none
         size_t net_bytes = 0;
-        float *prob = nullptr;          // ensemble accumulator [n,5,net_h,net_w]
+        float *prob = nullptr;          // ensemble accumulator [n,classes,net_h,net_w]
         size_t prob_bytes = 0;
     } lane[4];
     // host pipeline
@@ -275,6 +288,8 @@ static gs_status check_common(gs_espnet *const *models, int n_models, const floa
                "network size must be a positive multiple of 8 in both dimensions (got %dx%d)", net_h, net_w);
     for (int k = 0; k < n_models; ++k) {
         GS_REQUIRE(models[k] && espnet_is_full_net(models[k]), "model %d is not a full ESPNet handle (the crop entries need the decoder)", k);
+        GS_REQUIRE(espnet_classes(models[k]) == espnet_classes(models[0]), "model %d has %d classes, model 0 has %d", k,
+                   espnet_classes(models[k]), espnet_classes(models[0]));
         for (int i = 0; i < 3; ++i)
             GS_REQUIRE(stds[3 * k + i] != 0.0f, "model %d: std[%d] is zero", k, i);
     }
@@ -294,6 +309,7 @@ static gs_status run_batch(gs_espnet *const *models, int n_models, int lane, con
         GS_REQUIRE(lane < espnet_lanes(models[k]), "model %d has no lane %d (gs_espnet_set_lanes)", k, lane);
     CropPipe::LaneScratch &ls = pipe->lane[lane];
     const size_t npx = (size_t)net_h * net_w;
+    const int classes = espnet_classes(models[0]);
     gs_status st = grow(ls.f32, ls.f32_bytes, (size_t)n * 3 * npx * sizeof(float), "crop tensor");
     if (st != GS_OK) return st;
     if (!net_masks) {
@@ -302,7 +318,7 @@ static gs_status run_batch(gs_espnet *const *models, int n_models, int lane, con
         net_masks = ls.net;
     }
     if (n_models > 1) {
-        st = grow(ls.prob, ls.prob_bytes, (size_t)n * 5 * npx * sizeof(float), "ensemble accumulator");
+        st = grow(ls.prob, ls.prob_bytes, (size_t)n * classes * npx * sizeof(float), "ensemble accumulator");
         if (st != GS_OK) return st;
     }
     CropTable tab;
@@ -327,7 +343,7 @@ static gs_status run_batch(gs_espnet *const *models, int n_models, int lane, con
         }
         if (hist && k == 0) {
             a.hist_zero = hist;
-            a.hist_count = n * 5;
+            a.hist_count = n * classes;
         }
         hipLaunchKernelGGL(crops_prep_kernel, prep_grid, dim3(256), 0, s, tab, a);
         GS_HIP(hipGetLastError());
@@ -340,7 +356,13 @@ static gs_status run_batch(gs_espnet *const *models, int n_models, int lane, con
         long long gx = (max_hw + 8 * 1024 - 1) / (8 * 1024);   // about eight iterations per workgroup, never more than 512
         gx = std::max(gx, (max_hw + 512 * 1024 - 1) / (512 * 1024));
         gx = std::min(std::max(gx, 1ll), 65535ll);
-        hipLaunchKernelGGL(crops_back_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, s, tab, net_masks, net_h, net_w, packed_out, hist);
+        const dim3 grid((unsigned)gx, (unsigned)n);
+        switch ((classes + 4) / 5) {
+        case 1: hipLaunchKernelGGL(crops_back_kernel<1>, grid, dim3(256), 0, s, tab, net_masks, net_h, net_w, packed_out, hist, classes); break;
+        case 2: hipLaunchKernelGGL(crops_back_kernel<2>, grid, dim3(256), 0, s, tab, net_masks, net_h, net_w, packed_out, hist, classes); break;
+        case 3: hipLaunchKernelGGL(crops_back_kernel<3>, grid, dim3(256), 0, s, tab, net_masks, net_h, net_w, packed_out, hist, classes); break;
+        default: hipLaunchKernelGGL(crops_back_kernel<4>, grid, dim3(256), 0, s, tab, net_masks, net_h, net_w, packed_out, hist, classes); break;
+        }
         GS_HIP(hipGetLastError());
     }
     if (paste) {
@@ -458,6 +480,7 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
     for (int k = 0; k < n_models; ++k)
         if (espnet_lanes(models[k]) < 2) nl = 1;
     const size_t npx = (size_t)net_h * net_w;
+    const size_t ncl = (size_t)espnet_classes(models[0]);   // hist is [n_crops][classes]
     // which crops go into which batch, and the staging a batch needs (csrc/crop_plan.h: host-only, sanitised on its own)
     const CropBatchPlan plan = plan_crop_batches(heights, widths, n_crops, batch, MAXC);
     const std::vector<int> &starts = plan.starts;
@@ -501,11 +524,11 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
             fail(hipHostMalloc(reinterpret_cast<void **>(&s.hin), ci, hipHostMallocDefault), "hipHostMalloc");
             fail(hipHostMalloc(reinterpret_cast<void **>(&s.hout), co, hipHostMallocDefault), "hipHostMalloc");
             fail(hipHostMalloc(reinterpret_cast<void **>(&s.hnet), cn, hipHostMallocDefault), "hipHostMalloc");
-            fail(hipHostMalloc(reinterpret_cast<void **>(&s.hh), sizeof(unsigned long long) * 5 * cb, hipHostMallocDefault), "hipHostMalloc");
+            fail(hipHostMalloc(reinterpret_cast<void **>(&s.hh), sizeof(unsigned long long) * GS_MAX_CLASSES * cb, hipHostMallocDefault), "hipHostMalloc");
             fail(hipMalloc(reinterpret_cast<void **>(&s.din), ci), "hipMalloc");
             fail(hipMalloc(reinterpret_cast<void **>(&s.dout), co), "hipMalloc");
             fail(hipMalloc(reinterpret_cast<void **>(&s.dnet), cn), "hipMalloc");
-            fail(hipMalloc(reinterpret_cast<void **>(&s.dh), sizeof(unsigned long long) * 5 * cb), "hipMalloc");
+            fail(hipMalloc(reinterpret_cast<void **>(&s.dh), sizeof(unsigned long long) * GS_MAX_CLASSES * cb), "hipMalloc");
             fail(hipEventCreateWithFlags(&s.up, hipEventDisableTiming), "hipEventCreate");
             fail(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
             fail(hipEventCreateWithFlags(&s.down, hipEventDisableTiming), "hipEventCreate");
@@ -533,7 +556,7 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
         if (net_masks && !net_pinned)
             parallel_memcpy(net_masks + (size_t)s.first * npx, s.hnet, npx * s.count);
         if (hist && !hist_pinned)
-            std::memcpy(hist + (size_t)s.first * 5, s.hh, sizeof(unsigned long long) * 5 * s.count);
+            std::memcpy(hist + (size_t)s.first * ncl, s.hh, sizeof(unsigned long long) * ncl * s.count);
         s.first = -1;
     };
     int slot = 0, bi = 0;
@@ -605,8 +628,8 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
             fail(hipMemcpy2DAsync(net_pinned ? net_masks + (size_t)first * npx : s.hnet, npx, s.dnet, npx, npx, cnt, hipMemcpyDeviceToHost, compute),
                  "D2H copy");
         if (hist) {
-            const size_t b = sizeof(unsigned long long) * 5 * cnt;
-            fail(hipMemcpy2DAsync(hist_pinned ? hist + (size_t)first * 5 : s.hh, b, s.dh, b, b, 1, hipMemcpyDeviceToHost, compute), "D2H copy");
+            const size_t b = sizeof(unsigned long long) * ncl * cnt;
+            fail(hipMemcpy2DAsync(hist_pinned ? hist + (size_t)first * ncl : s.hh, b, s.dh, b, b, 1, hipMemcpyDeviceToHost, compute), "D2H copy");
         }
         fail(hipEventRecord(s.down, compute), "hipEventRecord");
         s.first = first;

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -67,6 +68,8 @@ struct PackedConv {   // float offsets into the device weight blob
 
 struct Model {
     int classes = 0, p = 0, q = 0;
+    int cp = 0;   // the padded class count the decoder kernels are instantiated for: 5 for the five-class networks (the fast path),
+                  // else `classes` rounded up to a multiple of four (espnet_kernels.h, "CLASS COUNTS")
     bool encoder_only = false;
     int device = 0, num_cus = 256;
 #ifdef GS_DIAG
@@ -279,7 +282,7 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
         GS_HIP(hipFree(m->ws));
         m->ws = nullptr;
     }
-    const int cls = m->classes;
+    const int cls = m->cp;   // padded class planes (the planes beyond m->classes stay zero)
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8;
     // comb_l2_l3 (planes 0..cls-1, written by dec3) and output0_cat (planes cls..cls+18, written by the stem) share one
     // buffer in the order of the decoder's torch.cat (Model.py:375), so conv CBR(19+classes, classes, 3) reads its input as
@@ -469,7 +472,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         a.W = W;
         if (hist && !m->encoder_only && (ens_mode == 0 || ens_mode >= 3)) {   // zeroed by the first kernel of the forward; the last one adds into it
             a.hist_zero = hist;
-            a.hist_count = n * CLS;
+            a.hist_count = n * m->classes;
         }
         if (in_format == GS_IN_U8_BGR_NHWC)
             hipLaunchKernelGGL(stem_kernel<true>, dim3(blocks_for((long long)n * H1 * ((W1 + STEM_PX - 1) / STEM_PX))), dim3(256), 0, s, a);
@@ -671,7 +674,8 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     }
 
     // ---- b3 + classifier (+ br + up_l3)  (Model.py:368-370)
-    L.run(K_DEC1, px3 * (256 * CLS * 2) + px3 * (CLS * CLS * 4 * 2), [&] {
+    const int ncls = m->classes;   // real class count (CLS is the padded one): algorithmic FLOPs, output widths
+    L.run(K_DEC1, px3 * (256 * ncls * 2) + px3 * (ncls * ncls * 4 * 2), [&] {
         Dec1Args a{};
         a.c0 = view(m->cc[0]);
         a.clast = view(m->cc[cur3]);
@@ -681,15 +685,18 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         a.out = view(m->o2c);
         a.enc_logits = m->encoder_only ? logits : nullptr;
         a.N = n;
-        hipLaunchKernelGGL((dec1_kernel<CLS, 16>), dim3((unsigned)(((long long)n * H3 * W3 + 63) / 64)), dim3(256), 0, s, a);
+        a.classes = ncls;
+        // (channel batch: 16 channels x (3 + CLS) scalar constants in flight fit the scalar registers for five classes only)
+        constexpr int CB = CLS <= 5 ? 16 : CLS <= 8 ? 8 : 4;
+        hipLaunchKernelGGL((dec1_kernel<CLS, CB>), dim3((unsigned)(((long long)n * H3 * W3 + 63) / 64)), dim3(256), 0, s, a);
         return GS_OK;
     });
     if (m->encoder_only)
         return L.st;
-    set_stage("up_l3", m->o2c, CLS);
+    set_stage("up_l3", m->o2c, ncls);
 
     // ---- level3_C + cat + BR (Model.py:372-373)
-    L.run(K_DEC2, px2 * (131 * CLS * 2), [&] {
+    L.run(K_DEC2, px2 * (131 * ncls * 2), [&] {
         Dec2Args a{};
         a.a1 = view(m->a1);
         a.raw = view(m->bb[0]);
@@ -701,12 +708,14 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         a.br = wb + m->cbr0;
         a.t = view(m->tt);
         a.N = n;
+        a.classes = ncls;
         hipLaunchKernelGGL(dec2_kernel<CLS>, dim3((unsigned)(((long long)n * H2 * W2 + 63) / 64)), dim3(256), 0, s, a);   // 64 pixels x 4 channel quarters
         return GS_OK;
     });
-    set_stage("combine_t", m->tt, 2 * CLS);
+    if (ncls == CLS)   // (with padding planes in between the two halves are not one contiguous stage)
+        set_stage("combine_t", m->tt, 2 * CLS);
     // ---- CBR(2c,c,3) + up_l2 (Model.py:373)
-    L.run(K_DEC3, px2 * (2 * CLS * 9 * CLS * 2) + px2 * (CLS * CLS * 4 * 2), [&] {
+    L.run(K_DEC3, px2 * (2 * ncls * 9 * ncls * 2) + px2 * (ncls * ncls * 4 * 2), [&] {
         Dec3Args a{};
         a.t = view(m->tt);
         a.wc = wb + m->wcc;
@@ -715,42 +724,94 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         a.bnu = wb + m->bnu2;
         a.e = view(m->ee);
         a.N = n;
+        a.classes = ncls;
         hipLaunchKernelGGL(dec3_kernel<CLS>, dim3(blocks_for((long long)n * H2 * W2)), dim3(256), 0, s, a);
         return GS_OK;
     });
-    set_stage("up_l2", m->ee, CLS);
+    set_stage("up_l2", m->ee, ncls);
     // ---- conv CBR(19+c,c,3) + classifier deconv + argmax + counts (Model.py:375-377, VisualizeResults_iou.py:128,151-155)
-    GS_DIAG_TRY((diag_two_kernel_tail<CLS>(m, L, n, H1, W1, logits, mask, hist, s, set_stage, dst_)));
-    L.run(K_DEC_TAIL, px1 * ((19 + CLS) * 9 * CLS * 2) + px1 * (CLS * CLS * 4 * 2), [&] {
-        DecTailArgs a{};
-        a.in = m->a0c.base;
-        a.in_sn = m->a0c.sn;
-        a.in_sc = m->a0c.sc;
-        a.in_pitch = m->a0c.pitch;
-        a.in_off = m->a0c.off;
-        a.in_img_bytes = (unsigned)(m->a0c.sn * sizeof(float));
-        a.wpack = wb + m->wtail;
-        a.logits = logits;
-        a.mask = mask;
-        a.hist = (ens_mode == 1 || ens_mode == 2) ? nullptr : hist;   // only the last member of an ensemble counts
-        a.prob = prob;
-        a.ens_mode = ens_mode;
-        a.ens_w = ens_w;
-        if (logits) {   // debug / test path: the half-resolution CBR output is kept as stage "conv"
-            a.ff = m->ff.base;
-            a.ff_sn = m->ff.sn;
-            a.ff_sc = m->ff.sc;
-            a.ff_pitch = m->ff.pitch;
-            a.ff_off = m->ff.off;
-        }
-        a.N = n;
-        a.H1 = H1;
-        a.W1 = W1;
-        return launch_dec_tail(a, m->num_cus, s);
-    });
-    if (logits)
-        set_stage("conv", m->ff, CLS);
+    if constexpr (CLS == 5) {
+        GS_DIAG_TRY((diag_two_kernel_tail<CLS>(m, L, n, H1, W1, logits, mask, hist, s, set_stage, dst_)));
+        L.run(K_DEC_TAIL, px1 * ((19 + CLS) * 9 * CLS * 2) + px1 * (CLS * CLS * 4 * 2), [&] {
+            DecTailArgs a{};
+            a.in = m->a0c.base;
+            a.in_sn = m->a0c.sn;
+            a.in_sc = m->a0c.sc;
+            a.in_pitch = m->a0c.pitch;
+            a.in_off = m->a0c.off;
+            a.in_img_bytes = (unsigned)(m->a0c.sn * sizeof(float));
+            a.wpack = wb + m->wtail;
+            a.logits = logits;
+            a.mask = mask;
+            a.hist = (ens_mode == 1 || ens_mode == 2) ? nullptr : hist;   // only the last member of an ensemble counts
+            a.prob = prob;
+            a.ens_mode = ens_mode;
+            a.ens_w = ens_w;
+            if (logits) {   // debug / test path: the half-resolution CBR output is kept as stage "conv"
+                a.ff = m->ff.base;
+                a.ff_sn = m->ff.sn;
+                a.ff_sc = m->ff.sc;
+                a.ff_pitch = m->ff.pitch;
+                a.ff_off = m->ff.off;
+            }
+            a.N = n;
+            a.H1 = H1;
+            a.W1 = W1;
+            return launch_dec_tail(a, m->num_cus, s);
+        });
+        if (logits)
+            set_stage("conv", m->ff, CLS);
+    } else {
+        // Any other class count (Model.py:311: `classes` is free, 20 by default): the 3x3 over the 19 + classes planes of the concat
+        // buffer as a plain conv_mfma launch (MFMA rows = the padded output channels, BN + PReLU in its epilogue), then the
+        // classifier deconvolution + argmax + counts (+ the ensemble's softmax accumulation) as a second kernel.
+        L.run(K_DEC_CONV, px1 * ((19 + ncls) * 9 * ncls * 2), [&] {
+            const ConvArgs ca = conv_args(m->a0c, wb + m->wconv, m->ff, nullptr, n);
+            constexpr int CINP = (19 + CLS + 3) / 4 * 4;
+            if constexpr (CLS <= 16)
+                return launch_vec<F_BNACT | POL_DEC_CONV, 16, 8, CINP, 9, 1, 1, CLS, CLS, 8, 3>(ca, m->num_cus, s);
+            else
+                return launch_vec<F_BNACT | POL_DEC_CONV, 32, 8, CINP, 9, 1, 1, CLS, CLS, 4, 3>(ca, m->num_cus, s);
+        });
+        set_stage("conv", m->ff, ncls);
+        L.run(K_DEC4, px1 * (ncls * ncls * 4 * 2), [&] {
+            Dec4Args a{};
+            a.f = view(m->ff);
+            a.wcl = wb + m->wclassifier;
+            a.logits = logits;
+            a.mask = mask;
+            a.hist = hist;
+            a.prob = prob;
+            a.ens_mode = ens_mode;
+            a.ens_w = ens_w;
+            a.N = n;
+            a.classes = ncls;
+            const dim3 grid(blocks_for(((long long)H1 * W1 + dec4_px<CLS>() - 1) / dec4_px<CLS>()), n);
+            if (ens_mode)
+                hipLaunchKernelGGL((dec4_kernel<CLS, true>), grid, dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL((dec4_kernel<CLS, false>), grid, dim3(256), 0, s, a);
+            return GS_OK;
+        });
+    }
     return L.st;
+}
+
+// the decoder kernels exist for the padded class counts 4, 5, 8, 12, 16, 20 (Model::cp)
+static gs_status forward_any(Model *m, const void *in, int in_format, int n, int H, int W, const float *mean, const float *stdv,
+                             float *logits, uint8_t *mask, unsigned long long *hist, hipStream_t s, float *prob = nullptr,
+                             int ens_mode = 0, float ens_w = 1.0f)
+{
+    switch (m->cp) {
+    case 5: return forward_impl<5>(m, in, in_format, n, H, W, mean, stdv, logits, mask, hist, s, prob, ens_mode, ens_w);
+    case 4: return forward_impl<4>(m, in, in_format, n, H, W, mean, stdv, logits, mask, hist, s, prob, ens_mode, ens_w);
+    case 8: return forward_impl<8>(m, in, in_format, n, H, W, mean, stdv, logits, mask, hist, s, prob, ens_mode, ens_w);
+    case 12: return forward_impl<12>(m, in, in_format, n, H, W, mean, stdv, logits, mask, hist, s, prob, ens_mode, ens_w);
+    case 16: return forward_impl<16>(m, in, in_format, n, H, W, mean, stdv, logits, mask, hist, s, prob, ens_mode, ens_w);
+    case 20: return forward_impl<20>(m, in, in_format, n, H, W, mean, stdv, logits, mask, hist, s, prob, ens_mode, ens_w);
+    }
+    set_error("internal: no decoder instantiation for %d padded classes", m->cp);
+    return GS_ERR_UNSUPPORTED;
 }
 
 static void free_pipeline(Model &m)
@@ -808,11 +869,12 @@ CropPipe *&espnet_crop_pipe(gs_espnet *h) { return h->crop_pipe; }
 int espnet_device(gs_espnet *h) { return h->m.device; }
 int espnet_is_full_net(gs_espnet *h) { return h->m.encoder_only ? 0 : 1; }
 int espnet_lanes(gs_espnet *h) { return 1 + (int)h->lanes.size(); }
-// the ensemble's fp32 probability accumulator [n][5][height][width], owned by the first member's handle
+int espnet_classes(gs_espnet *h) { return h->m.classes; }
+// the ensemble's fp32 probability accumulator [n][classes][height][width], owned by the first member's handle
 gs_status ensemble_scratch(gs_espnet *h, int n, int height, int width, float **prob)
 {
     Model &m0 = h->m;
-    const size_t need = (size_t)n * 5 * height * width * sizeof(float);
+    const size_t need = (size_t)n * m0.classes * height * width * sizeof(float);
     if (m0.prob_bytes < need) {
         if (m0.prob) {
             GS_HIP(hipDeviceSynchronize());
@@ -841,7 +903,7 @@ gs_status espnet_forward_ex(gs_espnet *h, int lane, const void *in, int in_forma
     GS_REQUIRE(!m.encoder_only || ens_mode == 0, "an ESPNet-C handle cannot be an ensemble member");
     gs_status st = layout_workspace(&m, n, height, width);
     if (st != GS_OK) return st;
-    return forward_impl<5>(&m, in, in_format, n, height, width, mean, stdv, logits, mask, hist, s, prob, ens_mode, ens_w);
+    return forward_any(&m, in, in_format, n, height, width, mean, stdv, logits, mask, hist, s, prob, ens_mode, ens_w);
 }
 }  // namespace gs
 
@@ -852,8 +914,10 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
 {
     GS_REQUIRE(blob && table && out && n_layers > 0, "gs_espnet_create: null argument");
     GS_REQUIRE(p >= 0 && q >= 0, "gs_espnet_create: p and q must be non-negative");
-    if (classes != 5) {
-        set_error("gs_espnet_create: kernels are instantiated for classes=5 only (got %d)", classes);
+    // Model.py:311,246: `classes` is free (20 by default).  The decoder kernels exist for 2..20 (padded to 4, 5, 8, 12, 16, 20
+    // planes: Model::cp); class maps are uint8 and a lane's per-class counters are sized for at most 20.
+    if (classes < 2 || classes > 20) {
+        set_error("gs_espnet_create: classes must be 2..20 (got %d)", classes);
         return GS_ERR_UNSUPPORTED;
     }
     int ndev = 0;
@@ -864,6 +928,7 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
     std::unique_ptr<gs_espnet> h(new gs_espnet());
     Model &m = h->m;
     m.classes = classes;
+    m.cp = classes == 5 ? 5 : (classes + 3) / 4 * 4;
     m.p = p;
     m.q = q;
     m.encoder_only = encoder_only != 0;
@@ -914,43 +979,102 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
     m.l3.resize(q);
     for (int i = 0; i < q; ++i)
         if (!pack_block(t, bb, e + "level3." + std::to_string(i), false, 3, m.l3[i], nullptr, 0, 0, next3(i + 1))) return GS_ERR_INVALID;
+    // ---- decoder: every piece is packed for cp class planes, zero beyond the model's c (espnet_kernels.h, "CLASS COUNTS")
+    const int cp = m.cp;
+    // [rows][cols][2][2] deconvolution weights -> [cp][cp][2][2]
+    auto pad_deconv = [&](const float *src) {
+        std::vector<float> o((size_t)cp * cp * 4, 0.0f);
+        for (int i = 0; i < c; ++i)
+            for (int o2 = 0; o2 < c; ++o2)
+                for (int k = 0; k < 4; ++k)
+                    o[((size_t)i * cp + o2) * 4 + k] = src[((size_t)i * c + o2) * 4 + k];
+        return o;
+    };
+    // folded BN (+ PReLU slope) [rows][C] -> [rows][cpn] through `map` (padded index -> source channel or -1): padding planes
+    // get scale 0, shift 0, slope 1, so they stay exact zeros
+    auto pad_bn = [&](const float *src, int C, int rows, int cpn, const std::function<int(int)> &map) {
+        std::vector<float> o((size_t)rows * cpn, 0.0f);
+        for (int k = 0; k < cpn; ++k) {
+            const int sc = map(k);
+            for (int r = 0; r < rows; ++r)
+                o[(size_t)r * cpn + k] = sc >= 0 ? src[(size_t)r * C + sc] : (r == 2 ? 1.0f : 0.0f);
+        }
+        return o;
+    };
+    auto ident = [&](int k) { return k < c ? k : -1; };
     if (!fold_bn(t, e + "b3.bn", e + "b3.act", 256, tmp.data())) return GS_ERR_INVALID;
     if (!(w = t.get(e + "classifier.conv.weight", {c, 256, 1, 1}))) return GS_ERR_INVALID;
     {
-        std::vector<float> pk(256 * 8, 0.0f);   // [channel][scale, shift, alpha, w0..w4]
+        const int rec = (3 + cp + 3) / 4 * 4;   // dec1_record<cp>
+        std::vector<float> pk((size_t)256 * rec, 0.0f);   // [channel][scale, shift, alpha, w0..]
         for (int ch = 0; ch < 256; ++ch) {
-            for (int j = 0; j < 3; ++j) pk[ch * 8 + j] = tmp[j * 256 + ch];
-            for (int k = 0; k < c; ++k) pk[ch * 8 + 3 + k] = w[k * 256 + ch];
+            for (int j = 0; j < 3; ++j) pk[(size_t)ch * rec + j] = tmp[j * 256 + ch];
+            for (int k = 0; k < c; ++k) pk[(size_t)ch * rec + 3 + k] = w[k * 256 + ch];
         }
         m.b3 = bb.push(pk.data(), pk.size());
         m.wcls = m.b3;
     }
     if (!m.encoder_only) {
         if (!fold_bn(t, "br", "", c, tmp.data(), false)) return GS_ERR_INVALID;
-        m.br = bb.push(tmp.data(), 2 * c);
+        {
+            const std::vector<float> v = pad_bn(tmp.data(), c, 2, cp, ident);
+            m.br = bb.push(v.data(), v.size());
+        }
         if (!(w = t.get("up_l3.0.weight", {c, c, 2, 2}))) return GS_ERR_INVALID;
-        m.wup3 = bb.push(w, (size_t)c * c * 4);
+        {
+            const std::vector<float> v = pad_deconv(w);
+            m.wup3 = bb.push(v.data(), v.size());
+        }
         if (!(w = t.get("level3_C.conv.weight", {c, 131, 1, 1}))) return GS_ERR_INVALID;
         {
-            std::vector<float> pk(131 * 8, 0.0f);
+            const int rec = (cp + 3) / 4 * 4;   // dec2_record<cp>
+            std::vector<float> pk((size_t)131 * rec, 0.0f);
             for (int ch = 0; ch < 131; ++ch)
-                for (int k = 0; k < c; ++k) pk[ch * 8 + k] = w[k * 131 + ch];
+                for (int k = 0; k < c; ++k) pk[(size_t)ch * rec + k] = w[k * 131 + ch];
             m.w3c = bb.push(pk.data(), pk.size());
         }
+        // combine_l2_l3: cat([level3_C out, up_l3 out]) (Model.py:373) lives in 2 * cp planes, each half padded on its own
+        auto cat2 = [&](int k) { return k < cp ? (k < c ? k : -1) : (k - cp < c ? c + k - cp : -1); };
         if (!fold_bn(t, "combine_l2_l3.0.bn", "combine_l2_l3.0.act", 2 * c, tmp.data())) return GS_ERR_INVALID;
-        m.cbr0 = bb.push(tmp.data(), 6 * c);
-        if (!(w = t.get("combine_l2_l3.1.conv.weight", {c, 2 * c, 3, 3}))) return GS_ERR_INVALID;
-        m.wcc = bb.push(w, (size_t)c * 2 * c * 9);
-        if (!fold_bn(t, "combine_l2_l3.1.bn", "combine_l2_l3.1.act", c, tmp.data())) return GS_ERR_INVALID;
-        m.bncc = bb.push(tmp.data(), 3 * c);
-        if (!(w = t.get("up_l2.0.weight", {c, c, 2, 2}))) return GS_ERR_INVALID;
-        m.wup2 = bb.push(w, (size_t)c * c * 4);
-        if (!fold_bn(t, "up_l2.1.bn", "up_l2.1.act", c, tmp.data())) return GS_ERR_INVALID;
-        m.bnu2 = bb.push(tmp.data(), 3 * c);
-        if (!(w = t.get("conv.conv.weight", {c, 19 + c, 3, 3}))) return GS_ERR_INVALID;
         {
-            // LDS image [tap][24 planes][c]: the planes of the concat buffer are in the order of the reference's
-            // torch.cat([comb_l2_l3, output0_cat]) (Model.py:375), so plane = cat channel
+            const std::vector<float> v = pad_bn(tmp.data(), 2 * c, 3, 2 * cp, cat2);
+            m.cbr0 = bb.push(v.data(), v.size());
+        }
+        if (!(w = t.get("combine_l2_l3.1.conv.weight", {c, 2 * c, 3, 3}))) return GS_ERR_INVALID;
+        {
+            std::vector<float> v((size_t)cp * 2 * cp * 9, 0.0f);
+            for (int k = 0; k < c; ++k)
+                for (int ch = 0; ch < 2 * cp; ++ch) {
+                    const int sc = cat2(ch);
+                    if (sc < 0) continue;
+                    for (int tap = 0; tap < 9; ++tap)
+                        v[((size_t)k * 2 * cp + ch) * 9 + tap] = w[((size_t)k * 2 * c + sc) * 9 + tap];
+                }
+            m.wcc = bb.push(v.data(), v.size());
+        }
+        if (!fold_bn(t, "combine_l2_l3.1.bn", "combine_l2_l3.1.act", c, tmp.data())) return GS_ERR_INVALID;
+        {
+            const std::vector<float> v = pad_bn(tmp.data(), c, 3, cp, ident);
+            m.bncc = bb.push(v.data(), v.size());
+        }
+        if (!(w = t.get("up_l2.0.weight", {c, c, 2, 2}))) return GS_ERR_INVALID;
+        {
+            const std::vector<float> v = pad_deconv(w);
+            m.wup2 = bb.push(v.data(), v.size());
+        }
+        if (!fold_bn(t, "up_l2.1.bn", "up_l2.1.act", c, tmp.data())) return GS_ERR_INVALID;
+        {
+            const std::vector<float> v = pad_bn(tmp.data(), c, 3, cp, ident);
+            m.bnu2 = bb.push(v.data(), v.size());
+        }
+        if (!(w = t.get("conv.conv.weight", {c, 19 + c, 3, 3}))) return GS_ERR_INVALID;
+        // plane `pl` of the concat buffer [comb_l2_l3 (cp planes) | output0_cat (19) | zero planes] <-> channel of the reference's
+        // torch.cat([comb_l2_l3, output0_cat]) (Model.py:375)
+        auto cat_ch = [&](int pl) { return pl < cp ? (pl < c ? pl : -1) : (pl - cp < 19 ? c + pl - cp : -1); };
+        if (!fold_bn(t, "conv.bn", "conv.act", c, tmp.data())) return GS_ERR_INVALID;
+        const std::vector<float> bn_conv = pad_bn(tmp.data(), c, 3, cp, ident);
+        if (cp == 5) {
+            // LDS image [tap][24 planes][c]: plane = cat channel
             const int npl = 19 + c;
             m.wconv = bb.reserve(conv_wfloats(npl, 9, 1, c, c, true));
             float *dst = bb.data.data() + m.wconv;
@@ -960,7 +1084,7 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
                     for (int co = 0; co < c; ++co)
                         dst[((size_t)tap * npl + pl) * c + co] = w[((size_t)co * (19 + c) + wch) * 9 + tap];
                 }
-            if (!fold_bn(t, "conv.bn", "conv.act", c, dst + (size_t)9 * npl * c)) return GS_ERR_INVALID;
+            std::memcpy(dst + (size_t)9 * npl * c, bn_conv.data(), sizeof(float) * 3 * c);
             // row-merged form (F_XMERGE): LDS image [ty][plane][row = tx*c + o]
             m.wconv_xm = bb.reserve(conv_wfloats(npl, 3, 1, c, c, true, false, true));
             float *dx = bb.data.data() + m.wconv_xm;
@@ -971,11 +1095,28 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
                         for (int co = 0; co < c; ++co)
                             dx[((size_t)ty * npl + pl) * (3 * c) + tx * c + co] = w[((size_t)co * (19 + c) + wch) * 9 + ty * 3 + tx];
                 }
-            if (!fold_bn(t, "conv.bn", "conv.act", c, dx + (size_t)3 * npl * 3 * c)) return GS_ERR_INVALID;
+            std::memcpy(dx + (size_t)3 * npl * 3 * c, bn_conv.data(), sizeof(float) * 3 * c);
+        } else {
+            // the generic tail's conv_mfma image [tap][CINP planes][cp rows] + BN: CINP = 19 + cp rounded up to the k-step
+            const int cinp = (19 + cp + 3) / 4 * 4;
+            m.wconv = bb.reserve(conv_wfloats(cinp, 9, 1, cp, cp, true));
+            float *dst = bb.data.data() + m.wconv;
+            for (int tap = 0; tap < 9; ++tap)
+                for (int pl = 0; pl < cinp; ++pl) {
+                    const int wch = cat_ch(pl);
+                    if (wch < 0) continue;
+                    for (int co = 0; co < c; ++co)
+                        dst[((size_t)tap * cinp + pl) * cp + co] = w[((size_t)co * (19 + c) + wch) * 9 + tap];
+                }
+            std::memcpy(dst + (size_t)9 * cinp * cp, bn_conv.data(), sizeof(float) * 3 * cp);
+            m.wconv_xm = m.wconv;
         }
         if (!(w = t.get("classifier.weight", {c, c, 2, 2}))) return GS_ERR_INVALID;
-        m.wclassifier = bb.push(w, (size_t)c * c * 4);
         {
+            const std::vector<float> v = pad_deconv(w);
+            m.wclassifier = bb.push(v.data(), v.size());
+        }
+        if (cp == 5) {
             // dec_tail image: A operands [ty][plane group][lane] (lane = k-group * 16 + MFMA row, row = tx*c + o),
             // then BN scale / shift / alpha of conv, then classifier.weight
             const float *wc = t.get("conv.conv.weight", {c, 19 + c, 3, 3});
@@ -989,7 +1130,7 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
                         dt[(ty * 6 + g) * 64 + lane] =
                             rho < 3 * c ? wc[(((size_t)(rho % c) * (19 + c) + ch) * 3 + ty) * 3 + rho / c] : 0.0f;
                     }
-            if (!fold_bn(t, "conv.bn", "conv.act", c, dt + DT_A_FLOATS)) return GS_ERR_INVALID;
+            std::memcpy(dt + DT_A_FLOATS, bn_conv.data(), sizeof(float) * 3 * c);
             std::memcpy(dt + DT_A_FLOATS + 16, w, sizeof(float) * c * c * 4);
         }
     }
@@ -1107,8 +1248,7 @@ gs_status gs_espnet_forward_lane(gs_espnet *h, int lane, const void *in, int in_
             GS_REQUIRE(std[i] != 0.0f, "std[%d] is zero", i);
     st = layout_workspace(&m, n, height, width);
     if (st != GS_OK) return st;
-    return forward_impl<5>(&m, in, in_format, n, height, width, mean, std, logits, mask, hist,
-                           static_cast<hipStream_t>(hip_stream));
+    return forward_any(&m, in, in_format, n, height, width, mean, std, logits, mask, hist, static_cast<hipStream_t>(hip_stream));
 }
 
 gs_status gs_espnet_read_stage(gs_espnet *h, const char *stage, int image, float *dst, size_t cap, int dims[3])
@@ -1247,6 +1387,8 @@ gs_status gs_espnet_ensemble_forward(gs_espnet *const *models, int n_models, con
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     for (int k = 0; k < n_models; ++k) {
         GS_REQUIRE(models[k] && !models[k]->m.encoder_only, "ensemble member %d is not a full ESPNet", k);
+        GS_REQUIRE(models[k]->m.classes == models[0]->m.classes, "ensemble member %d has %d classes, member 0 has %d", k,
+                   models[k]->m.classes, models[0]->m.classes);
         for (int i = 0; i < 3; ++i)
             GS_REQUIRE(stds[3 * k + i] != 0.0f, "ensemble member %d: std[%d] is zero", k, i);
     }
@@ -1275,6 +1417,7 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
     if (st != GS_OK) return st;
     if (batch > n_tiles) batch = n_tiles;
     const size_t in_b = (size_t)height * width * 3, out_b = (size_t)height * width;
+    const size_t ncl = (size_t)h->m.classes;   // hist is [n_tiles][classes]
     constexpr int NSLOT = 4;
     const int nl = h->lanes.empty() ? 1 : 2;   // batches alternate between (at most) two lanes, each on its own compute stream
     // caller buffers that are already page-locked (hipHostMalloc / hipHostRegister) are DMA'd in place;
@@ -1320,10 +1463,10 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
             Slot &s = sl[i];
             fail(hipHostMalloc(reinterpret_cast<void **>(&s.hin), in_b * batch, hipHostMallocDefault), "hipHostMalloc");
             fail(hipHostMalloc(reinterpret_cast<void **>(&s.hout), out_b * batch, hipHostMallocDefault), "hipHostMalloc");
-            fail(hipHostMalloc(reinterpret_cast<void **>(&s.hh), sizeof(unsigned long long) * 5 * batch, hipHostMallocDefault), "hipHostMalloc");
+            fail(hipHostMalloc(reinterpret_cast<void **>(&s.hh), sizeof(unsigned long long) * GS_MAX_CLASSES * batch, hipHostMallocDefault), "hipHostMalloc");
             fail(hipMalloc(reinterpret_cast<void **>(&s.din), in_b * batch), "hipMalloc");
             fail(hipMalloc(reinterpret_cast<void **>(&s.dout), out_b * batch), "hipMalloc");
-            fail(hipMalloc(reinterpret_cast<void **>(&s.dh), sizeof(unsigned long long) * 5 * batch), "hipMalloc");
+            fail(hipMalloc(reinterpret_cast<void **>(&s.dh), sizeof(unsigned long long) * GS_MAX_CLASSES * batch), "hipMalloc");
             fail(hipEventCreateWithFlags(&s.up, hipEventDisableTiming), "hipEventCreate");
             fail(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
             fail(hipEventCreateWithFlags(&s.down, hipEventDisableTiming), "hipEventCreate");
@@ -1340,7 +1483,7 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         if (fail(hipEventSynchronize(s.down), "hipEventSynchronize")) return;
         if (!out_pinned) {
             parallel_memcpy(masks + (size_t)s.first * out_b, s.hout, out_b * s.count);
-            if (hist) std::memcpy(hist + (size_t)s.first * 5, s.hh, sizeof(unsigned long long) * 5 * s.count);
+            if (hist) std::memcpy(hist + (size_t)s.first * ncl, s.hh, sizeof(unsigned long long) * ncl * s.count);
         }
         s.first = -1;
     };
@@ -1395,12 +1538,12 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
         // copy wave sends a launch into a second round -- measured 3.29 ms per batch with a 48-workgroup copy kernel, 2.96
         // without the download, 2.93 without any copy.
         uint8_t *hdst = out_pinned ? masks + (size_t)first * out_b : s.hout;
-        unsigned long long *hhdst = (out_pinned && hist) ? hist + (size_t)first * 5 : s.hh;
+        unsigned long long *hhdst = (out_pinned && hist) ? hist + (size_t)first * ncl : s.hh;
         if (!(pskip & 2))
             fail(hipMemcpy2DAsync(hdst, out_b, s.dout, out_b, out_b, cnt, hipMemcpyDeviceToHost, compute), "D2H copy");
         if (hist || !out_pinned)
-            fail(hipMemcpy2DAsync(hhdst, sizeof(unsigned long long) * 5 * cnt, s.dh, sizeof(unsigned long long) * 5 * cnt,
-                                  sizeof(unsigned long long) * 5 * cnt, 1, hipMemcpyDeviceToHost, compute), "D2H copy");
+            fail(hipMemcpy2DAsync(hhdst, sizeof(unsigned long long) * ncl * cnt, s.dh, sizeof(unsigned long long) * ncl * cnt,
+                                  sizeof(unsigned long long) * ncl * cnt, 1, hipMemcpyDeviceToHost, compute), "D2H copy");
         fail(hipEventRecord(s.down, compute), "hipEventRecord");
         stamp("d2h");
         s.first = first;

@@ -332,14 +332,31 @@ cat_b2_kernel(const ActV o1, const ActV o10, const ActV inp2, const float *bnp, 
 // b3 -> encoder classifier -> (br BN -> up_l3 deconv).  One thread per 1/8-scale pixel.
 // reference: Model.py:368-370 (b3: cat([output2_0, output2]) -> BR(256); classifier C(256,classes,1);
 // br = BatchNorm2d(classes); up_l3 = ConvTranspose2d(classes,classes,2,stride=2)).
+// CLASS COUNTS.  The decoder kernels are instantiated for a PADDED class count CLS -- 5 (the shipped networks: the fast path, whose
+// code and bits are those of rounds 1-4) or a multiple of four up to 20 -- and take the model's real count (Model.py:311: any
+// `classes`, 20 by default) at run time: weights, BN parameters and activation planes beyond it are zero (packed so by
+// gs_espnet_create), stores and the argmax stop at it.  A zero term leaves an fmaf chain unchanged, so a real class's value is
+// the one an exact-width kernel would compute.
+template <int CLS>
+__device__ __forceinline__ int real_classes(int classes)
+{
+    return CLS == 5 ? 5 : classes;   // (folds away on the fast path)
+}
+// floats per channel record [scale, shift, alpha, w[0..CLS)] of dec1, and per weight row of dec2: whole float4s
+template <int CLS>
+constexpr int dec1_record() { return (3 + CLS + 3) / 4 * 4; }
+template <int CLS>
+constexpr int dec2_record() { return (CLS + 3) / 4 * 4; }
+
 struct Dec1Args {
     ActV c0, clast;      // output2_0, output2 (128 channels each)
-    const float *b3w;    // [256][8]: folded b3 {scale, shift, alpha} + encoder.classifier.conv.weight[0..CLS)[c]
+    const float *b3w;    // [256][dec1_record]: folded b3 {scale, shift, alpha} + encoder.classifier.conv.weight[0..CLS)[c]
     const float *br;     // folded br scale/shift [2][CLS]
     const float *wup;    // up_l3.0.weight [CLS][CLS][2][2]
     ActV out;            // output2_c: CLS channels at 1/4 scale
-    float *enc_logits;   // encoder-only mode: [N][CLS][H3][W3], else null
+    float *enc_logits;   // encoder-only mode: [N][classes][H3][W3], else null
     int N;
+    int classes;         // the model's class count (<= CLS)
 };
 
 // A workgroup = 64 pixels x 4 waves: wave w sums channels 64w .. 64w+63 of its lane's pixel, the four partial sums meet in
@@ -384,7 +401,7 @@ __global__ void __launch_bounds__(256) dec1_kernel(const Dec1Args a)
 #pragma unroll
         for (int j = 0; j < CB; ++j) {
             // per-channel constants packed [c][8] = {scale, shift, alpha, w[0..CLS)}: one scalar load per channel
-            const float *pc = a.b3w + (w * 64 + c0 + j) * 8;
+            const float *pc = a.b3w + (w * 64 + c0 + j) * dec1_record<CLS>();
             const float t = cur[j] * pc[0] + pc[1];
             const float v = prelu(t, pc[2]);
 #pragma unroll
@@ -406,15 +423,32 @@ __global__ void __launch_bounds__(256) dec1_kernel(const Dec1Args a)
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = (s[k] + part[0][k][lane]) + (part[1][k][lane] + part[2][k][lane]);
+    const int ncls = real_classes<CLS>(a.classes);
     if (a.enc_logits) {
 #pragma unroll
         for (int k = 0; k < CLS; ++k)
-            a.enc_logits[(((long long)n * CLS + k) * H3 + y) * W3 + x] = s[k];
+            if (k < ncls)
+                a.enc_logits[(((long long)n * ncls + k) * H3 + y) * W3 + x] = s[k];
         return;
     }
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = s[k] * a.br[k] + a.br[CLS + k];
+    if constexpr (CLS != 5) {
+        // one output class at a time (a rolled loop): unrolled, the CLS * CLS * 4 weights were all fetched up front -- 1 600
+        // registers' worth at twenty classes, 4 KB of scratch per lane
+        for (int o = 0; o < ncls; ++o) {
+            float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < CLS; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    t[k] = fmaf(s[i], a.wup[(i * CLS + o) * 4 + k], t[k]);
+            *reinterpret_cast<float2 *>(at(a.out, n, o, 2 * y, 2 * x)) = make_float2(t[0], t[1]);
+            *reinterpret_cast<float2 *>(at(a.out, n, o, 2 * y + 1, 2 * x)) = make_float2(t[2], t[3]);
+        }
+        return;
+    }
     float up[CLS][2][2];   // arithmetic first, stores last (see stem_kernel)
 #pragma unroll
     for (int o = 0; o < CLS; ++o)
@@ -443,10 +477,11 @@ struct Dec2Args {
     const float *b2;     // BN + PReLU (b2 folded [3][131]) of this raw block output, applied here on load
     int raw_c0, raw_cn;
     ActV o2c;            // output2_c (CLS)
-    const float *w3c;    // level3_C.conv.weight packed [131][8] (first CLS of each row used)
-    const float *br;     // combine_l2_l3.0 folded [3][2*CLS]
-    ActV t;              // out: 2*CLS channels
+    const float *w3c;    // level3_C.conv.weight packed [131][dec2_record] (first CLS of each row used)
+    const float *br;     // combine_l2_l3.0 folded [3][2*CLS]: padded channel k <-> cat channel k (level3_C's), CLS + k <-> classes + k
+    ActV t;              // out: 2*CLS planes in that padded order
     int N;
+    int classes;
 };
 
 // A workgroup = 64 pixels x 4 waves, as dec1_kernel: wave w sums channels 32w .. 32w+31 (wave 3 goes on through 128..130), the
@@ -475,7 +510,7 @@ __global__ void __launch_bounds__(256) dec2_kernel(const Dec2Args a)
 #pragma unroll 16
         for (int c = cb; c < cb + 32; ++c) {
             const float v = bn_prelu(ld_stream<NT_DEC2_LD>(at(a.raw, n, c - a.raw_c0, y, x)), a.b2, 131, c);
-            const float *pc = a.w3c + c * 8;   // level3_C weights packed [c][8]: one scalar load per channel
+            const float *pc = a.w3c + c * dec2_record<CLS>();   // level3_C weights packed [c][record]: one scalar load per channel
 #pragma unroll
             for (int k = 0; k < CLS; ++k)
                 s[k] = fmaf(pc[k], v, s[k]);
@@ -484,7 +519,7 @@ __global__ void __launch_bounds__(256) dec2_kernel(const Dec2Args a)
 #pragma unroll 16
         for (int c = cb; c < cb + 32; ++c) {
             const float v = ld_stream<NT_DEC2_LD>(at(a.a1, n, c, y, x));
-            const float *pc = a.w3c + c * 8;
+            const float *pc = a.w3c + c * dec2_record<CLS>();
 #pragma unroll
             for (int k = 0; k < CLS; ++k)
                 s[k] = fmaf(pc[k], v, s[k]);
@@ -494,7 +529,7 @@ __global__ void __launch_bounds__(256) dec2_kernel(const Dec2Args a)
 #pragma unroll
         for (int c = 128; c < 131; ++c) {
             const float v = ld_stream<NT_DEC2_LD>(at(a.a1, n, c, y, x));
-            const float *pc = a.w3c + c * 8;
+            const float *pc = a.w3c + c * dec2_record<CLS>();
 #pragma unroll
             for (int k = 0; k < CLS; ++k)
                 s[k] = fmaf(pc[k], v, s[k]);
@@ -517,9 +552,11 @@ __global__ void __launch_bounds__(256) dec2_kernel(const Dec2Args a)
         tv[k] = bn_prelu(s[k], a.br, 2 * CLS, k);
         tv[CLS + k] = bn_prelu(*at(a.o2c, n, k, y, x), a.br, 2 * CLS, CLS + k);
     }
+    const int ncls = real_classes<CLS>(a.classes);
 #pragma unroll
     for (int k = 0; k < 2 * CLS; ++k)
-        *at(a.t, n, k, y, x) = tv[k];
+        if (k % CLS < ncls)
+            *at(a.t, n, k, y, x) = tv[k];
 }
 
 // combine_l2_l3[1] CBR(2*classes,classes,3) -> up_l2 deconv -> BR(classes).  One thread per
@@ -532,6 +569,7 @@ struct Dec3Args {
     const float *bnu;    // up_l2.1 folded [3][CLS]
     ActV e;              // out: comb_l2_l3 at 1/2 scale, CLS channels
     int N;
+    int classes;
 };
 
 template <int CLS>
@@ -548,7 +586,10 @@ __global__ void __launch_bounds__(256) dec3_kernel(const Dec3Args a)
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = 0.0f;
-    for (int c = 0; c < 2 * CLS; ++c)
+    const int ncls = real_classes<CLS>(a.classes);
+    for (int c = 0; c < 2 * CLS; ++c) {
+        if (CLS != 5 && c % CLS >= ncls)
+            continue;   // (uniform) a padding plane: zeros times zero weights
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -558,6 +599,7 @@ __global__ void __launch_bounds__(256) dec3_kernel(const Dec3Args a)
                 for (int k = 0; k < CLS; ++k)
                     s[k] = fmaf(a.wc[((k * 2 * CLS + c) * 3 + ky) * 3 + kx], v, s[k]);
             }
+    }
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = bn_prelu(s[k], a.bnc, CLS, k);
@@ -578,35 +620,49 @@ __global__ void __launch_bounds__(256) dec3_kernel(const Dec3Args a)
     for (int o = 0; o < CLS; ++o)
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
-            *reinterpret_cast<float2 *>(at(a.e, n, o, 2 * y + dy, 2 * x)) = make_float2(up[o][dy][0], up[o][dy][1]);
+            if (o < ncls)
+                *reinterpret_cast<float2 *>(at(a.e, n, o, 2 * y + dy, 2 * x)) = make_float2(up[o][dy][0], up[o][dy][1]);
 }
 
 // classifier ConvTranspose2d(classes,classes,2,2) -> logits -> first-max argmax -> uint8 mask ->
 // per-class pixel counts, on the output of conv CBR(19+classes,classes,3) (which runs on the matrix
-// cores, CFG_DEC_CONV).  One thread per 1/2-scale pixel (= a 2x2 block of output pixels).
+// cores, a conv_mfma_kernel instantiation).  One thread per 1/2-scale pixel (= a 2x2 block of output pixels).
 // reference: Model.py:377; VisualizeResults_iou.py:128 (argmax), :151-155 (counts)
+// This two-kernel tail is what every class count other than 5 runs (the five-class networks take dec_tail.h's fused kernel):
+// round 1's tail, generalised.  ENS: the ensemble of BASELINE cfg 5 (definition in DESIGN.md) -- prob [N][classes][H][W]
+// accumulates ens_w * softmax(logits) over the member models exactly as dec_tail_kernel does for five classes (mode 1: first
+// member stores, 2: a middle member adds, 3: the last adds and goes on to the first-max argmax of the sum, 4: a single member).
 struct Dec4Args {
     ActV f;              // concat_features: conv CBR output, CLS channels at 1/2 scale
     const float *wcl;    // classifier.weight [CLS][CLS][2][2]
-    float *logits;       // [N][CLS][H][W] or null
+    float *logits;       // [N][classes][H][W] or null
     unsigned char *mask; // [N][H][W] or null
-    unsigned long long *hist;   // [N][CLS] or null
+    unsigned long long *hist;   // [N][classes] or null
+    float *prob;         // ENS: the accumulator
+    int ens_mode;
+    float ens_w;
     int N;
+    int classes;
 };
 
-constexpr int DEC4_PX = 4;
+// half-scale pixels per thread: four for few classes (see below); with many classes one pixel's deconvolution is already CLS^2 * 4
+// FMAs and the unrolled body of four would be too large to unroll at all (the per-pixel arrays would then live in scratch)
 template <int CLS>
+constexpr int dec4_px() { return CLS <= 8 ? 4 : CLS <= 12 ? 2 : 1; }
+template <int CLS, bool ENS>
 __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
 {
     __shared__ unsigned int lhist[CLS];
     const int H1 = a.f.H, W1 = a.f.W;
     const int H = 2 * H1, W = 2 * W1;
     const int n = blockIdx.y;   // one block never straddles two images
+    const int ncls = real_classes<CLS>(a.classes);
+    constexpr int DEC4_PX = dec4_px<CLS>();
     // classifier weights through LDS: read from global memory they were re-fetched with vector loads after every
     // mask / logits store (possible aliasing), 395 loads per thread
     __shared__ float wl[CLS * CLS * 4];
-    if (threadIdx.x < CLS * CLS * 4)
-        wl[threadIdx.x] = a.wcl[threadIdx.x];
+    for (int i = threadIdx.x; i < CLS * CLS * 4; i += 256)
+        wl[i] = a.wcl[i];
     if (threadIdx.x < CLS)
         lhist[threadIdx.x] = 0;
     __syncthreads();
@@ -646,30 +702,62 @@ __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
                     for (int i = 0; i < CLS; ++i)
                         t = fmaf(s[q][i], wl[((i * CLS + o) * 2 + dy) * 2 + dx], t);
                     lg[o] = t;
-                    if (o == 0 || t > best) {   // strict '>' : first maximum wins
+                    if (!ENS && o < ncls && (o == 0 || t > best)) {   // strict '>' : first maximum wins
                         best = t;
                         bi = o;
                     }
                 }
-                if (a.logits && live[q]) {
+                const long long pix = ((long long)(2 * y + dy)) * W + 2 * x + dx;
+                if (ENS) {
+                    // prob (+)= ens_w * softmax(logits): max-shifted expf, one division per class (dec_tail.h's arithmetic)
+                    float mx = -3.4e38f;
 #pragma unroll
                     for (int o = 0; o < CLS; ++o)
-                        a.logits[(((long long)n * CLS + o) * H + 2 * y + dy) * W + 2 * x + dx] = lg[o];
+                        if (o < ncls)
+                            mx = fmaxf(mx, lg[o]);
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int o = 0; o < CLS; ++o)
+                        if (o < ncls) {
+                            lg[o] = expf(lg[o] - mx);
+                            sum += lg[o];
+                        }
+                    bool first = true;
+#pragma unroll
+                    for (int o = 0; o < CLS; ++o)
+                        if (o < ncls && live[q]) {
+                            float pr = lg[o] / sum * a.ens_w;
+                            float *pp = a.prob + ((long long)n * ncls + o) * H * W + pix;
+                            if (a.ens_mode == 2 || a.ens_mode == 3)
+                                pr = *pp + pr;
+                            if (a.ens_mode == 1 || a.ens_mode == 2)
+                                *pp = pr;
+                            else if (first || pr > best) {
+                                best = pr;
+                                bi = o;
+                            }
+                            first = false;
+                        }
+                } else if (a.logits && live[q]) {
+#pragma unroll
+                    for (int o = 0; o < CLS; ++o)
+                        if (o < ncls)
+                            a.logits[((long long)n * ncls + o) * H * W + pix] = lg[o];
                 }
                 m[dx] = (unsigned char)bi;
                 cls_of[q][dy * 2 + dx] = live[q] ? bi : -1;   // -1: no pixel here
             }
-            if (a.mask && live[q])
+            if (a.mask && live[q] && (!ENS || a.ens_mode >= 3))
                 st_stream<NT_DEC4_ST>(reinterpret_cast<unsigned short *>(a.mask + ((long long)n * H + 2 * y + dy) * W + 2 * x),
                                       (unsigned short)(m[0] | (m[1] << 8)));
         }
     }
-    if (a.hist) {
+    if (a.hist && (!ENS || a.ens_mode >= 3)) {
         // per-class counts by wave ballot + popcount: one LDS atomic per class per wave (a per-pixel
         // LDS atomic on five hot words serialised the whole workgroup)
 #pragma unroll
         for (int k = 0; k < CLS; ++k) {
-            unsigned cnt = 0;
+            unsigned cnt = 0;   // (a padding class is never an argmax: its count is zero)
 #pragma unroll
             for (int q = 0; q < DEC4_PX; ++q)
 #pragma unroll
@@ -679,8 +767,8 @@ __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
                 atomicAdd(&lhist[k], cnt);
         }
         __syncthreads();
-        if (threadIdx.x < CLS && lhist[threadIdx.x])
-            atomicAdd(&a.hist[(long long)n * CLS + threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
+        if (threadIdx.x < ncls && lhist[threadIdx.x])
+            atomicAdd(&a.hist[(long long)n * ncls + threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
     }
 }
 

@@ -67,6 +67,7 @@ void crop_pipe_destroy(CropPipe *p);               // crops.hip; called by gs_es
 int espnet_device(gs_espnet *h);
 int espnet_is_full_net(gs_espnet *h);
 int espnet_lanes(gs_espnet *h);
+int espnet_classes(gs_espnet *h);
 gs_status ensemble_scratch(gs_espnet *h, int n, int height, int width, float **prob);
 gs_status espnet_forward_ex(gs_espnet *h, int lane, const void *in, int in_format, int n, int height, int width, const float *mean,
                             const float *stdv, float *logits, uint8_t *mask, unsigned long long *hist, float *prob, int ens_mode,

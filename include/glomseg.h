@@ -57,6 +57,13 @@ typedef struct gs_layer_desc {
 
 typedef struct gs_espnet gs_espnet;
 
+/* Class counts: ESPNet(classes, p, q) takes any `classes` (Model.py:311; the constructor's default is 20, the shipped networks
+ * have 5, VisualizeResults_iou.py:315 passes --classes through).  This library builds 2 <= classes <= GS_MAX_CLASSES; anything
+ * else is refused by gs_espnet_create with GS_ERR_UNSUPPORTED (class maps are uint8; the per-class counters and the padded
+ * decoder instantiations stop at 20).  Five classes run the fused decoder tail; other counts a two-kernel tail that is
+ * slower per tile.  Every `hist` below is [n][classes] and every ensemble accumulator [n][classes][h][w]. */
+#define GS_MAX_CLASSES 20
+
 /* Build a model handle on the current HIP device from a host fp32 weight blob.
  * classes/p/q as ESPNet(classes, p, q) (Model.py:311); encoder_only != 0 builds
  * ESPNet_Encoder (ESPNet-C, Model.py:246) whose table uses keys without the "encoder." prefix. */
@@ -146,7 +153,7 @@ typedef struct gs_paste_target {
 
 /* Device-resident form, stream-ordered on lane `lane`: n <= GS_MAX_CROPS_PER_CALL crops packed in `packed_in` (device), their
  * descriptors in HOST memory (they travel as kernel arguments).  Any of net_masks (device uint8 [n,net_h,net_w], the map the
- * reference scores at network resolution, :202), packed_out (device, crop-size maps at out_off), hist (device uint64 [n,5],
+ * reference scores at network resolution, :202), packed_out (device, crop-size maps at out_off), hist (device uint64 [n,classes],
  * counts of the crop-size maps) and paste may be NULL, but not all of them. */
 gs_status gs_espnet_segment_crops(gs_espnet *h, int lane, const uint8_t *packed_in, const gs_crop_desc *descs, int n,
                                   const float mean[3], const float std[3], int net_h, int net_w, uint8_t *net_masks,
@@ -164,7 +171,7 @@ gs_status gs_espnet_ensemble_segment_crops(gs_espnet *const *models, int n_model
  * widths[i],3] in host memory (page-locked buffers are DMA'd in place, pageable ones staged through pinned slots by a few
  * threads); up to `batch` (<= GS_MAX_CROPS_PER_CALL) crops per step; uploads on a stream of their own, batches alternate
  * between two compute streams (and two lanes when the handle has them), results come back by SDMA.  Outputs, each optional:
- * masks[i] (host uint8 [heights[i],widths[i]]), net_masks (host uint8 [n_crops,net_h,net_w]), hist (host uint64 [n_crops,5],
+ * masks[i] (host uint8 [heights[i],widths[i]]), net_masks (host uint8 [n_crops,net_h,net_w]), hist (host uint64 [n_crops,classes],
  * counts of the crop-size maps), paste + x1/y1 (level-0 origins).  n_models == 1 is the plain model; > 1 the ensemble.
  * A list shorter than four full batches is cut into a small first batch (a seventh of the list, at least eight crops: its
  * upload is the pipeline's fill) and three equal ones.

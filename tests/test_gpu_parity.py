@@ -1407,3 +1407,123 @@ def test_pinned_block_query(torch_mod):
     assert lib.gs_host_block_is_pinned(ctypes.c_void_p(a.data_ptr() + 4096), a.numel()) == 0      # runs past the allocation's end
     b = np.zeros(1 << 20, dtype=np.uint8)
     assert lib.gs_host_block_is_pinned(ctypes.c_void_p(b.ctypes.data), b.size) == 0               # pageable
+
+
+CLASS_CASES = [(20, 2, 3), (7, 2, 3), (2, 1, 1), (12, 2, 2), (16, 1, 2), (3, 2, 8)]
+
+
+@pytest.mark.parametrize("classes,p,q", CLASS_CASES)
+def test_other_class_counts_against_the_reference(torch_mod, classes, p, q):
+    """the HIP path at class counts other than 5 against logits and class maps of the REFERENCE's ESPNet(classes, p, q) with the
+    same seeded random weights (tests/golden/classes.npz; the first case is the constructor's default, `ESPNet()` = (20, 2, 3),
+    Model.py:311): logits <= 5e-4 relative, class-map disagreement <= 2e-3; the uint8 entry's mask is the first-max argmax of
+    those logits (:128) and its counts the bincount of that mask over `classes` bins (:151-155)"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.engine import EspnetEngine
+    z = load_golden("classes.npz")
+    tag = "c%d" % classes
+    sd = random_state_dict(p, q, classes=classes, seed=1000 + classes)
+    eng = EspnetEngine(sd, classes=classes, p=p, q=q)
+    mean, std = [float(v) for v in z["mean"]], [float(v) for v in z["std"]]
+    tiles = torch.from_numpy(np.stack([z["tile_" + tag]] * 3)).cuda()           # a batch: every image the same answer
+    mask, hist, logits = eng.segment(tiles, mean, std, want_logits=True)
+    ref = z["logits_" + tag]
+    got = logits.cpu().numpy()
+    assert got.shape == (3,) + ref.shape and hist.shape == (3, classes)
+    assert np.abs(got[0] - ref).max() <= 5e-4 * max(1.0, float(np.abs(ref).max()))
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+    m = mask.cpu().numpy()
+    assert (m[0] != z["mask_" + tag]).mean() <= 2e-3
+    assert np.array_equal(m[0], logits[0].max(0)[1].byte().cpu().numpy())      # first maximum wins
+    assert np.array_equal(hist[0].cpu().numpy(), np.bincount(m[0].ravel(), minlength=classes))
+    # mask-only call (no logits): the same mask and counts
+    m2, h2, _ = eng.segment(tiles, mean, std)
+    assert torch.equal(m2, mask) and torch.equal(h2, hist)
+    eng.close()
+
+
+def test_model_shim_with_the_constructor_defaults(torch_mod):
+    """`Net.ESPNet()` and `Net.ESPNet_Encoder()` with NO arguments -- the reference's defaults (20, 2, 3) / (20, 5, 3),
+    Model.py:311,246 -- run on cuda:0 against the reference's logits"""
+    torch = torch_mod
+    import glomeruli_segmentation_amd.Model as Net
+    from oracle import espnet_oracle as orc
+    z = load_golden("classes.npz")
+    mean, std = [float(v) for v in z["mean"]], [float(v) for v in z["std"]]
+    model = Net.ESPNet()
+    sd = random_state_dict(2, 3, classes=20, seed=1020)
+    msg = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    assert not msg.missing_keys and not msg.unexpected_keys
+    model = model.to("cuda:0").eval()
+    x = torch.from_numpy(orc.preprocess(z["tile_c20"], mean, std)[None]).to("cuda:0")
+    out = model(x)
+    ref = z["logits_c20"]
+    assert out.shape == (1, 20, 48, 104)
+    assert np.abs(out[0].cpu().numpy() - ref).max() <= 5e-4 * max(1.0, float(np.abs(ref).max()))
+    assert (out[0].max(0)[1].byte().cpu().numpy() != z["mask_c20"]).mean() <= 2e-3
+    enc = Net.ESPNet_Encoder()
+    sde = {n[len("encoder."):]: v for n, v in random_state_dict(5, 3, classes=20, seed=2020).items() if n.startswith("encoder.")}
+    msg = enc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sde.items()})
+    assert not msg.missing_keys and not msg.unexpected_keys
+    enc = enc.to("cuda:0").eval()
+    oute = enc(torch.from_numpy(orc.preprocess(z["tile_enc"], mean, std)[None]).to("cuda:0"))
+    refe = z["logits_enc"]
+    assert oute.shape == (1, 20, 6, 13)
+    assert np.abs(oute[0].cpu().numpy() - refe).max() <= 5e-4 * max(1.0, float(np.abs(refe).max()))
+
+
+def test_other_class_counts_crops_ensemble_and_host_pipeline(torch_mod):
+    """seven classes through the other entries: the host tile pipeline (hist [n,7]), the batched crop entry (counts of the crop-size
+    maps over seven bins, oracle chain), a two-member ensemble on tiles and on crops against the definition evaluated by the
+    oracle; class-count mismatches and counts outside 2..20 are refused"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd import _lib
+    from glomeruli_segmentation_amd.engine import EspnetEngine, ensemble_segment, segment_crops_host
+    from glomeruli_segmentation_amd.synth import noise_tile
+    from oracle import espnet_oracle as orc
+    from oracle import image_oracle as io
+    C = 7
+    sds = [random_state_dict(1, 2, classes=C, seed=70 + k) for k in range(2)]
+    ms = [((120.0, 130.0, 110.0), (60.0, 55.0, 70.0)), ((100.0, 140.0, 120.0), (50.0, 65.0, 60.0))]
+    engs = [EspnetEngine(sd, classes=C, p=1, q=2) for sd in sds]
+    tiles = np.stack([noise_tile(400 + k, 64, 128) for k in range(5)])
+    # host pipeline == resident
+    mh, hh = engs[0].segment_host(tiles, ms[0][0], ms[0][1], batch=2)
+    mr, hr, _ = engs[0].segment(torch.from_numpy(tiles).cuda(), ms[0][0], ms[0][1])
+    assert np.array_equal(mh, mr.cpu().numpy()) and np.array_equal(hh, hr.cpu().numpy()) and hh.shape == (5, C)
+    assert all(np.array_equal(hh[i], np.bincount(mh[i].ravel(), minlength=C)) for i in range(5))
+    assert (mh >= 5).any()                                     # classes beyond the five-class range do occur
+    # crops
+    crops = _crops([(40, 90), (64, 128), (130, 70)], 700)
+    r = engs[0].segment_crops(crops, ms[0][0], ms[0][1], 64, 128, batch=2, want_net_maps=True)
+    agree = total = 0
+    for i, c in enumerate(crops):
+        xo = io.normalise_then_resize(c, ms[0][0], ms[0][1], 128, 64)
+        ref_net = orc.argmax(orc.espnet_forward(xo, sds[0], 1, 2))
+        agree += int((ref_net == r["net_maps"][i]).sum())
+        total += ref_net.size
+        assert np.array_equal(io.resize_nearest(r["net_maps"][i], c.shape[1], c.shape[0]), r["masks"][i])
+        assert np.array_equal(np.bincount(r["masks"][i].ravel(), minlength=C), r["counts"][i])
+    assert agree / total >= 0.995, agree / total
+    # ensemble of two on tiles: mean of softmax, first-max argmax (DESIGN.md), evaluated by the oracle
+    em, eh = ensemble_segment(engs, torch.from_numpy(tiles[:2]).cuda(), ms)
+    em = em.cpu().numpy()
+    bad = 0
+    for i in range(2):
+        ref_mask, prob = orc.ensemble_mask(tiles[i], sds, ms, 1, 2)
+        top2 = np.sort(prob, axis=0)[-2:]
+        bad += int(((em[i] != ref_mask) & ((top2[1] - top2[0]) > 1e-4)).sum())
+        assert np.array_equal(eh[i].cpu().numpy(), np.bincount(em[i].ravel(), minlength=C))
+    assert bad == 0
+    # ... and on crops: network-sized crops give exactly the tile ensemble's masks
+    rc = segment_crops_host(engs, ms, [tiles[0], tiles[1]], 64, 128, batch=2)
+    assert np.array_equal(rc["masks"][0], em[0]) and np.array_equal(rc["masks"][1], em[1])
+    # refused: members that disagree on the class count; class counts outside 2..20
+    e5 = EspnetEngine(load_weights(1))
+    with pytest.raises(_lib.GlomsegError):
+        ensemble_segment([engs[0], e5], torch.from_numpy(tiles[:1]).cuda(), ms)
+    for bad_c in (1, 21):
+        with pytest.raises(_lib.GlomsegError):
+            EspnetEngine(random_state_dict(1, 1, classes=bad_c, seed=1), classes=bad_c, p=1, q=1)
+    for e in engs + [e5]:
+        e.close()

@@ -110,3 +110,38 @@ def test_other_depths_against_the_reference(p, q):
     ref = z["logits_p%d_q%d" % (p, q)]
     assert lg.shape == ref.shape
     assert np.abs(lg - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+CLASS_CASES = [(20, 2, 3), (7, 2, 3), (2, 1, 1), (12, 2, 2), (16, 1, 2), (3, 2, 8)]
+
+
+@pytest.mark.parametrize("classes,p,q", CLASS_CASES)
+def test_other_class_counts_against_the_reference(classes, p, q):
+    """ESPNet(classes, p, q) of the REFERENCE for class counts other than the shipped 5 -- the first case is the constructor's
+    default `ESPNet()` = (20, 2, 3), Model.py:311 -- with seeded random weights (tests/golden/make_golden_classes.py): the
+    oracle's decoder at any width, logits and first-max class map (VisualizeResults_iou.py:128)"""
+    from conftest import load_golden, random_state_dict
+    from oracle import espnet_oracle as orc
+    z = load_golden("classes.npz")
+    assert [tuple(r[:3]) for r in z["cases"]] == CLASS_CASES
+    sd = random_state_dict(p, q, classes=classes, seed=1000 + classes)
+    tag = "c%d" % classes
+    lg, mask, hist = orc.segment_tile(z["tile_" + tag], sd, [float(v) for v in z["mean"]], [float(v) for v in z["std"]], p, q)
+    ref = z["logits_" + tag]
+    assert lg.shape == ref.shape and lg.shape[0] == classes
+    assert np.abs(lg - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+    assert (mask != z["mask_" + tag]).mean() <= 2e-3
+    assert hist.shape == (classes,) and int(hist.sum()) == mask.size
+
+
+def test_encoder_default_arguments_against_the_reference():
+    """ESPNet-C built as the reference's `ESPNet_Encoder()` = (classes 20, p 5, q 3) (Model.py:246)"""
+    from conftest import load_golden, random_state_dict
+    from oracle import espnet_oracle as orc
+    z = load_golden("classes.npz")
+    sd = {n[len("encoder."):]: v for n, v in random_state_dict(5, 3, classes=20, seed=2020).items() if n.startswith("encoder.")}
+    x = orc.preprocess(z["tile_enc"], [float(v) for v in z["mean"]], [float(v) for v in z["std"]])
+    out = orc.espnet_encoder_forward(x, sd, 5, 3)
+    ref = z["logits_enc"]
+    assert out.shape == ref.shape == (20, 6, 13)
+    assert np.abs(out - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))
