@@ -66,21 +66,37 @@ constexpr bool kDtNoEpi = false;
 #ifndef DT_MAIN_WAVES
 #define DT_MAIN_WAVES 8
 #endif
-template <int CLS, int NRUN, int MODE, int WAVES>
+// EXCH (round 5): the strips of a row are cut at multiples of 128 columns WITHOUT overlap and the waves that hold horizontally
+// adjacent strips of one band -- a "team" of 1, 2, 4 or 8 waves of one workgroup -- hand each other the two values per class a
+// finished row needs from across the cut (the left neighbour's tx = 0 partial sums of its last column, the right neighbour's
+// tx = 2 sums of its first) through a two-slot LDS mailbox.  Against the overlapping 126-column strips this (a) covers a
+// 512-column row with four strips and no narrow rest strip (one launch instead of two), (b) makes every operand load a whole
+// 128-byte line (the 126-column strips start one float before a line: five lines fetched for four), and (c) puts the waves
+// that touch neighbouring lines in one workgroup.  Every output is the same (z0 + z1) + z2 of the same partial sums as before:
+// same bits.  A team's outer edges are the image's: the sums of the zero halo column are exact zeros and are written as such.
+template <int CLS, int NRUN, int MODE, int WAVES, bool EXCH = false>
 __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs a)
 {
     constexpr bool DBG = MODE == 1, ENS = MODE == 2;
     using DT = DecTailGeom<CLS, NRUN>;
-    constexpr int P = DT::P, NG = DT::NG, TS = DT::TS, XS = DT::XS, IMGS = DT::IMGS, CW = DT::CW, LPI = DT::LPI;
+    constexpr int P = DT::P, NG = DT::NG, TS = DT::TS, IMGS = DT::IMGS, CW = DT::CW, LPI = DT::LPI;
+    constexpr int XS = EXCH ? CW : DT::XS;   // output pixels per strip
+    static_assert(!EXCH || NRUN == 8, "the exchanging form is for full-width (128-column) strips");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     if (tid < 128)
         lds[tid] = tid < 116 ? a.wpack[DT_A_FLOATS + tid] : 0.0f;
+    // EXCH: behind the tiles, mailbox [wave][slot = row parity][16] and one row counter per wave
+    float *mbox = lds + 128 + WAVES * (16 * TS);
+    int *rows_done = reinterpret_cast<int *>(mbox + WAVES * 32);
+    if (EXCH && tid < WAVES)
+        rows_done[tid] = 0;
     __syncthreads();
     const int lane = tid & 63, j = lane & 15, kq = lane >> 4;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *tile = lds + 128 + wid * (16 * TS);
     static_assert(WAVES % 4 == 0, "whole waves per SIMD");
+    int epoch = 0;   // EXCH: rows this wave has finished (every wave of a team finishes the same rows in the same order)
 
     float A[3][NG];
 #pragma unroll
@@ -106,12 +122,18 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
     if (DT_PRIO && wid >= WAVES / 2)
         __builtin_amdgcn_s_setprio(1);
     // (a launch with fewer tasks than wave slots is spread over more CUs, a.wu waves of each taking tasks: launch_dec_tail_p)
+    // EXCH: tasks are (image, band) pairs taken by TEAMS (a.team waves: wave t of a team owns strip t); a.wu counts the teams
+    // of a workgroup that take tasks
+    const int team_sz = EXCH ? a.team : 1;
+    const int team = EXCH ? wid / team_sz : wid;
+    const int sidx = EXCH ? wid - team * team_sz : 0;
+    const bool has_left = EXCH && sidx > 0, has_right = EXCH && sidx + 1 < a.nstrips;
     const int nwaves = gridDim.x * a.wu;
-    for (int task = wid < a.wu ? blockIdx.x * a.wu + wid : a.total_tasks; task < a.total_tasks; task += nwaves) {
+    for (int task = (team < a.wu && (!EXCH || sidx < a.nstrips)) ? blockIdx.x * a.wu + team : a.total_tasks; task < a.total_tasks; task += nwaves) {
         const int col = task / a.bands;
         const int b = task - col * a.bands;
-        const int ig = col / a.nstrips;
-        const int s = col - ig * a.nstrips;
+        const int ig = EXCH ? col : col / a.nstrips;
+        const int s = EXCH ? sidx : col - ig * a.nstrips;
         const int n0 = ig * IMGS;                 // first image of the task
         const int nimg = min(IMGS, a.N - n0);     // (the last group may be short: its spare column blocks recompute the last image)
         // every band has exactly R = 3k+2 rows; the last one is shifted up to end at the image bottom and re-computes
@@ -122,7 +144,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
         const int x0 = a.xbase + XS * s;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.in + (long long)n0 * a.in_sn), 0, a.in_img_bytes * (unsigned)nimg, 0x00020000);
-        const int sbase = (a.in_off + x0 - 1) * 4;   // column x0-1 of row 0; row -1 is the zero halo row
+        const int sbase = (a.in_off + x0 - (EXCH ? 0 : 1)) * 4;   // column x0-1 (EXCH: x0, a whole line) of row 0; row -1 is the zero halo row
         // (uniform) offset of column block p: block p % NRUN of image n0 + p / NRUN -- added to the scalar offset of a load
         int roffp[NRUN == 8 ? 1 : P];
         if (NRUN < 8) {
@@ -199,7 +221,7 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    tile[(4 * kq + r) * TS + 16 * p + j] = acc[SL][p][r];
+                    tile[(4 * kq + r) * TS + 16 * p + j + (EXCH ? 1 : 0)] = acc[SL][p][r];   // (EXCH: tile column t = strip column + 1)
             // a zero the compiler cannot fold into the next MFMA's C operand: `mfma d, a, b, 0` writes a fresh register
             // range and the three accumulator sets then rotate through copies at the loop head
             float zero = 0.0f;
@@ -210,6 +232,38 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (EXCH) {
+                // across the cuts: tile column 0 <- the left neighbour's tx = 0 sums of ITS last column (its tile column 128),
+                // tile column 129 <- the right neighbour's tx = 2 sums of its first (its column 1).  Published through a
+                // mailbox slot per row parity: a wave writes row e + 2's values only after its neighbours have published row
+                // e + 1, i.e. after they have read row e's.  Waits are bounded: a team's waves are all resident (one
+                // workgroup) and nobody waits before publishing, so the bound is never met unless the kernel is wrong.
+                const int par = epoch & 1;
+                float *mine = mbox + (wid * 2 + par) * 16;
+                // (the lane index behind the opaque zero: hoisted out of the band loop, the per-lane addresses of this block
+                // would each hold a register for the whole kernel, and the mask-only form has none to spare)
+                const int ln = lane + coff;
+                if (ln < 10)
+                    mine[ln] = ln < 5 ? tile[ln * TS + 128] : tile[(ln + 5) * TS + 1];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0)
+                    __hip_atomic_store(&rows_done[wid], epoch + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (has_left)
+                    for (int spin = 0; __hip_atomic_load(&rows_done[wid - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= epoch && spin < (1 << 22); ++spin)
+                        __builtin_amdgcn_s_sleep(1);
+                if (has_right)
+                    for (int spin = 0; __hip_atomic_load(&rows_done[wid + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= epoch && spin < (1 << 22); ++spin)
+                        __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (ln < 5)
+                    tile[ln * TS] = has_left ? mbox[((wid - 1) * 2 + par) * 16 + ln] : 0.0f;
+                else if (ln < 10)
+                    tile[(ln + 5) * TS + 129] = has_right ? mbox[((wid + 1) * 2 + par) * 16 + ln] : 0.0f;
+                ++epoch;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             // lane l owns the output pixels m = 2q, 2q+1 (q = l % LPI) of the strip of image n0 + l / LPI:
             // out[o][m] = Z[o][m] + Z[5+o][m+1] + Z[10+o][m+2]
             const int gi = lane / LPI, m0 = 2 * (lane % LPI);
@@ -453,6 +507,61 @@ static gs_status launch_dec_tail_p(DecTailArgs a, int num_cus, hipStream_t strea
     return GS_OK;
 }
 
+// The exchanging form (EXCH): rows of 65 .. 1024 half-resolution pixels as ceil(W1 / 128) aligned strips taken by teams of waves,
+// ONE launch, no rest strip.
+#ifndef CFG_DEC_TAIL_EXCH
+#define CFG_DEC_TAIL_EXCH 1
+#endif
+static gs_status launch_dec_tail_exch(DecTailArgs a, int num_cus, hipStream_t stream)
+{
+    constexpr int WAVES = 8;
+    using DT = DecTailGeom<5, 8>;
+    a.xbase = 0;
+    a.nstrips = cdiv(a.W1, DT::CW);
+    a.team = a.nstrips <= 1 ? 1 : a.nstrips <= 2 ? 2 : a.nstrips <= 4 ? 4 : 8;
+    const int tpw = WAVES / a.team;             // teams per workgroup
+    const int slots = num_cus * tpw;
+    const int cols = a.N;                       // one image per task
+    int bands = slots / cols;
+    if (bands < 1) bands = 1;
+    int k3 = (cdiv(a.H1, bands) - 2 + 2) / 3;   // as launch_dec_tail_p: bands of R = 3k+2 rows, about one round of tasks
+    if (k3 < 0) k3 = 0;
+    while (k3 > 0 && 3 * k3 + 2 > a.H1) --k3;
+    if (k3 > 169) k3 = 169;                     // 12-bit count fields: R <= 509
+    a.k3 = k3;
+    a.R = 3 * k3 + 2;
+    a.bands = cdiv(a.H1, a.R);
+    a.total_tasks = cols * a.bands;
+    if ((long long)a.N * 4 * a.H1 * a.W1 >= (1ll << 32)) {
+        set_error("dec_tail: batch of %d tiles of %dx%d exceeds the 32-bit offsets of the mask descriptor", a.N, 2 * a.H1, 2 * a.W1);
+        return GS_ERR_UNSUPPORTED;
+    }
+    const size_t lds_bytes = (size_t)(128 + WAVES * 16 * DT::TS + WAVES * 32 + WAVES) * sizeof(float);
+    const int mode = a.ens_mode ? 2 : a.logits ? 1 : 0;
+    auto kern = mode == 2 ? dec_tail_kernel<5, 8, 2, WAVES, true> : mode == 1 ? dec_tail_kernel<5, 8, 1, WAVES, true> : dec_tail_kernel<5, 8, 0, WAVES, true>;
+    static std::mutex mu;
+    static std::map<int, bool> attr_done;
+    int dev = 0;
+    GS_HIP(hipGetDevice(&dev));
+    dev = dev * 3 + mode;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_done[dev]) {
+            GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            attr_done[dev] = true;
+        }
+    }
+    int grid = num_cus;
+    a.wu = tpw;
+    if (a.total_tasks < grid * tpw) {   // small batches: as few teams per workgroup as cover the tasks on all CUs (team 0 first:
+        a.wu = cdiv(a.total_tasks, grid);   // its waves sit on different SIMDs)
+        grid = cdiv(a.total_tasks, a.wu);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, a);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
 // Full-width strips (126 output columns, eight MFMA column blocks) in one launch; the narrow rest of the row, if any,
 // in a second one that packs the rest strips of 8 / NRUN images into every task.  (Round 4 built the rest strips into the main
 // launch twice -- as a second task list of the same waves, and as extra workgroups behind the main grid on a block-uniform
@@ -461,6 +570,10 @@ static gs_status launch_dec_tail_p(DecTailArgs a, int num_cus, hipStream_t strea
 // 2048 main tasks end together, so the rest tasks find no idle tail to fill.  Not kept.)
 gs_status launch_dec_tail(DecTailArgs a, int num_cus, hipStream_t stream)
 {
+    // rows of 65 .. 1024 pixels: aligned 128-column strips, neighbours exchange across the cuts (one launch).  Narrower rows
+    // pack several images into a wave, wider ones have more strips than a workgroup has waves: the overlapping strips below.
+    if (CFG_DEC_TAIL_EXCH && a.W1 > 64 && a.W1 <= 1024)
+        return launch_dec_tail_exch(a, num_cus, stream);
     constexpr int XS = DecTailGeom<5, 8>::XS;
     const int full_strips = a.W1 / XS, rest = a.W1 - full_strips * XS;
     if (full_strips > 0) {

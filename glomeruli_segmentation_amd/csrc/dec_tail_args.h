@@ -29,7 +29,8 @@ struct DecTailArgs {
     int xbase, nstrips;   // this launch covers strips of 16P-2 output columns starting at column xbase
     int bands, R, k3;     // bands of R = 3*k3 + 2 output rows
     int total_tasks;
-    int wu;               // waves of a workgroup that take tasks (all of them unless there are fewer tasks than wave slots)
+    int wu;               // waves (exchanging form: teams) of a workgroup that take tasks (all of them unless there are fewer tasks than slots)
+    int team;             // exchanging form (dec_tail.h, EXCH): waves per team = strips per row rounded up to a power of two
 };
 
 constexpr int DT_A_FLOATS = 18 * 64;
