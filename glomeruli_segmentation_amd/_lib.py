@@ -44,6 +44,11 @@ class PasteTarget(ctypes.Structure):
                 ("sx_lut", ctypes.c_void_p), ("sy_lut", ctypes.c_void_p)]
 
 
+class CropOverlay(ctypes.Structure):
+    _fields_ = [("palette_rgb", ctypes.c_void_p), ("n_colours", ctypes.c_int32), ("wa", ctypes.c_float), ("wb", ctypes.c_float),
+                ("out_bgr", ctypes.POINTER(ctypes.c_void_p))]
+
+
 class KernelTime(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 64), ("total_ms", ctypes.c_double), ("launches", ctypes.c_int64),
                 ("flops_per_tile", ctypes.c_double)]
@@ -72,7 +77,7 @@ PROTOTYPES = {
                                          ctypes.POINTER(PasteTarget), _P]),
     "gs_espnet_segment_crops_host": (_I, [ctypes.POINTER(_P), _I, ctypes.POINTER(_P), ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _FP, _FP,
                                      _I, _I, _I, ctypes.POINTER(_P), _P, _P, ctypes.POINTER(PasteTarget), ctypes.POINTER(_I),
-                                     ctypes.POINTER(_I)]),
+                                     ctypes.POINTER(_I), ctypes.POINTER(CropOverlay)]),
     "gs_plan_crop_batches": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _I, ctypes.POINTER(_I), _I, ctypes.POINTER(_I)]),
     "gs_host_block_is_pinned": (_I, [_P, ctypes.c_size_t]),
     "gs_espnet_ensemble_forward": (_I, [ctypes.POINTER(_P), _I, _P, _I, _I, _I, _FP, _FP, _P, _P, _P]),

@@ -142,6 +142,62 @@ crops_back_kernel(const CropTable t, const unsigned char *net, int net_h, int ne
     }
 }
 
+// Palette colouring + cv2.addWeighted of every crop of the batch (VisualizeResults_iou.py:139-146): four pixels per thread -- one
+// dword of the crop-size class map, three dwords of BGR in, three out.  The two products and their sum are rounded separately
+// (__fmul_rn / __fadd_rn: no fused multiply-add), so the bytes are those of numpy's float32 arithmetic.
+struct OverlayArgs {
+    const unsigned char *crops;   // packed BGR crops (gs_crop_desc::in_off)
+    const unsigned char *maps;    // packed crop-size class maps (out_off)
+    unsigned char *out;           // packed overlays, at in_off
+    float wa, wb;
+    int n_colours;
+    unsigned char pal[GS_MAX_PALETTE * 3];   // RGB rows
+};
+
+__global__ void __launch_bounds__(256) crops_overlay_kernel(const CropTable t, const OverlayArgs a)
+{
+    const int i = blockIdx.y;
+    const long long hw = (long long)t.d[i].h * t.d[i].w;
+    const unsigned char *src = a.crops + t.d[i].in_off, *cls = a.maps + t.d[i].out_off;
+    unsigned char *dst = a.out + t.d[i].in_off;
+    for (long long base = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; base < hw; base += (long long)gridDim.x * 1024) {
+        const int np = hw - base < 4 ? (int)(hw - base) : 4;
+        unsigned cw = 0, pw[3] = {0, 0, 0}, ow[3] = {0, 0, 0};   // bytes little-endian in dwords
+        if (np == 4) {   // (in_off / out_off are multiples of 256 and base of 4: aligned dwords)
+            cw = *reinterpret_cast<const unsigned *>(cls + base);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                pw[k] = reinterpret_cast<const unsigned *>(src + base * 3)[k];
+        } else {
+            for (int k = 0; k < np; ++k)
+                cw |= (unsigned)cls[base + k] << (8 * k);
+            for (int k = 0; k < np * 3; ++k)
+                pw[k >> 2] |= (unsigned)src[base * 3 + k] << (8 * (k & 3));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = (int)((cw >> (8 * k)) & 0xffu);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const int bi = k * 3 + ch;
+                const float pix = (float)((pw[bi >> 2] >> (8 * (bi & 3))) & 0xffu);
+                // palette rows are RGB, the image is BGR (classMap_numpy_color[...] = [b, g, r], :143)
+                const float col = c < a.n_colours ? (float)a.pal[c * 3 + (2 - ch)] : 0.0f;
+                const float v = __fadd_rn(__fmul_rn(pix, a.wa), __fmul_rn(col, a.wb));
+                ow[bi >> 2] |= (unsigned)fminf(fmaxf(rintf(v), 0.0f), 255.0f) << (8 * (bi & 3));   // saturate_cast<uchar>(cvRound)
+            }
+        }
+        if (np == 4) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                reinterpret_cast<unsigned *>(dst + base * 3)[k] = ow[k];
+        } else {
+            for (int k = 0; k < np * 3; ++k)
+                dst[base * 3 + k] = (unsigned char)(ow[k >> 2] >> (8 * (k & 3)));
+        }
+    }
+}
+
 // per-byte maximum into a map that other crops of the same launch (or of the other compute stream) may be writing
 __device__ __forceinline__ void byte_max(unsigned char *p, unsigned v)
 {
@@ -203,13 +259,15 @@ struct CropPipe {
     // host pipeline
     struct Slot {
         unsigned char *hin = nullptr, *din = nullptr, *hout = nullptr, *dout = nullptr, *hnet = nullptr, *dnet = nullptr;
+        unsigned char *hov = nullptr, *dov = nullptr;   // overlays (allocated on first use, sized like the packed input)
+        bool ov_direct = false;
         unsigned long long *hh = nullptr, *dh = nullptr;
         hipEvent_t up = nullptr, done = nullptr, down = nullptr;
         int first = -1, count = 0;
         bool out_direct = false;
         std::vector<gs_crop_desc> descs;
     } sl[4];
-    size_t cap_in = 0, cap_out = 0, cap_net = 0;
+    size_t cap_in = 0, cap_out = 0, cap_net = 0, cap_ov = 0;
     int cap_batch = 0;
     hipStream_t h2d = nullptr, compute[2] = {nullptr, nullptr};
 };
@@ -225,12 +283,14 @@ static void free_slots(CropPipe &p)
         if (s.dout) hipFree(s.dout);
         if (s.dnet) hipFree(s.dnet);
         if (s.dh) hipFree(s.dh);
+        if (s.hov) hipHostFree(s.hov);
+        if (s.dov) hipFree(s.dov);
         if (s.up) hipEventDestroy(s.up);
         if (s.done) hipEventDestroy(s.done);
         if (s.down) hipEventDestroy(s.down);
         s = CropPipe::Slot();
     }
-    p.cap_in = p.cap_out = p.cap_net = 0;
+    p.cap_in = p.cap_out = p.cap_net = p.cap_ov = 0;
     p.cap_batch = 0;
 }
 
@@ -299,7 +359,8 @@ static gs_status check_common(gs_espnet *const *models, int n_models, const floa
 // One batch, everything on stream s: the table is complete (offsets within packed_in / packed_out).
 static gs_status run_batch(gs_espnet *const *models, int n_models, int lane, const unsigned char *packed_in, const gs_crop_desc *descs,
                            int n, const float *means, const float *stds, int net_h, int net_w, unsigned char *net_masks,
-                           unsigned char *packed_out, unsigned long long *hist, const gs_paste_target *paste, hipStream_t s)
+                           unsigned char *packed_out, unsigned long long *hist, const gs_paste_target *paste, hipStream_t s,
+                           const gs_crop_overlay *overlay = nullptr, unsigned char *overlay_out = nullptr)
 {
     CropPipe *pipe = pipe_of(models[0]);
     GS_REQUIRE(pipe, "out of host memory");
@@ -363,6 +424,19 @@ static gs_status run_batch(gs_espnet *const *models, int n_models, int lane, con
         case 3: hipLaunchKernelGGL(crops_back_kernel<3>, grid, dim3(256), 0, s, tab, net_masks, net_h, net_w, packed_out, hist, classes); break;
         default: hipLaunchKernelGGL(crops_back_kernel<4>, grid, dim3(256), 0, s, tab, net_masks, net_h, net_w, packed_out, hist, classes); break;
         }
+        GS_HIP(hipGetLastError());
+    }
+    if (overlay && overlay_out) {   // needs the crop-size maps: the caller passes packed_out with it
+        OverlayArgs oa{};
+        oa.crops = packed_in;
+        oa.maps = packed_out;
+        oa.out = overlay_out;
+        oa.wa = overlay->wa;
+        oa.wb = overlay->wb;
+        oa.n_colours = overlay->n_colours;
+        std::memcpy(oa.pal, overlay->palette_rgb, (size_t)overlay->n_colours * 3);
+        const long long gx = std::min(std::max((max_hw + 8 * 1024 - 1) / (8 * 1024), 1ll), 65535ll);
+        hipLaunchKernelGGL(crops_overlay_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, s, tab, oa);
         GS_HIP(hipGetLastError());
     }
     if (paste) {
@@ -458,14 +532,20 @@ int gs_host_block_is_pinned(const void *p, size_t bytes) { return p && host_bloc
 gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, const uint8_t *const *crops, const int *heights,
                                        const int *widths, int n_crops, const float *means, const float *stds, int net_h, int net_w,
                                        int batch, uint8_t *const *masks, uint8_t *net_masks, unsigned long long *hist,
-                                       const gs_paste_target *paste, const int *x1, const int *y1)
+                                       const gs_paste_target *paste, const int *x1, const int *y1, const gs_crop_overlay *overlay)
 {
     gs_status st = check_common(models, n_models, means, stds, net_h, net_w);
     if (st != GS_OK) return st;
     GS_REQUIRE(crops && heights && widths && n_crops > 0, "segment_crops_host: null crop list");
     GS_REQUIRE(batch > 0, "batch must be positive");
-    GS_REQUIRE(masks || net_masks || hist || paste, "nothing to compute: every output is NULL");
+    GS_REQUIRE(masks || net_masks || hist || paste || overlay, "nothing to compute: every output is NULL");
     GS_REQUIRE(!paste || (x1 && y1), "a paste target needs the crops' level-0 origins");
+    if (overlay) {
+        GS_REQUIRE(overlay->palette_rgb && overlay->out_bgr && overlay->n_colours >= 1 && overlay->n_colours <= GS_MAX_PALETTE,
+                   "overlay: null palette / outputs or a table of %d colours (1 .. %d)", overlay->n_colours, GS_MAX_PALETTE);
+        for (int i = 0; i < n_crops; ++i)
+            GS_REQUIRE(overlay->out_bgr[i], "overlay: crop %d has no output buffer", i);
+    }
     st = check_paste(paste);
     if (st != GS_OK) return st;
     for (int i = 0; i < n_crops; ++i) {
@@ -542,6 +622,22 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
         p.cap_net = cn;
         p.cap_batch = cb;
     }
+    if (overlay && p.cap_ov < p.cap_in) {   // overlay staging: as large as the packed input, made when first asked for
+        fail(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        for (int i = 0; i < NSLOT && rc == GS_OK; ++i) {
+            CropPipe::Slot &s = p.sl[i];
+            if (s.hov) hipHostFree(s.hov);
+            if (s.dov) hipFree(s.dov);
+            s.hov = s.dov = nullptr;
+            fail(hipHostMalloc(reinterpret_cast<void **>(&s.hov), p.cap_in, hipHostMallocDefault), "hipHostMalloc");
+            fail(hipMalloc(reinterpret_cast<void **>(&s.dov), p.cap_in), "hipMalloc");
+        }
+        if (rc != GS_OK) {
+            free_slots(p);
+            return rc;
+        }
+        p.cap_ov = p.cap_in;
+    }
     for (auto &s : p.sl)
         s.first = -1;
     const bool net_pinned = net_masks && host_is_pinned(net_masks), hist_pinned = hist && host_is_pinned(hist);
@@ -552,6 +648,10 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
         if (masks && !s.out_direct)
             parallel_jobs(s.count, 4, [&](int j) {
                 std::memcpy(masks[s.first + j], s.hout + s.descs[j].out_off, (size_t)s.descs[j].h * s.descs[j].w);
+            });
+        if (overlay && !s.ov_direct)
+            parallel_jobs(s.count, 4, [&](int j) {
+                std::memcpy(overlay->out_bgr[s.first + j], s.hov + s.descs[j].in_off, (size_t)s.descs[j].h * s.descs[j].w * 3);
             });
         if (net_masks && !net_pinned)
             parallel_memcpy(net_masks + (size_t)s.first * npx, s.hnet, npx * s.count);
@@ -572,10 +672,13 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
         fill_crop_descs(heights, widths, x1, y1, first, cnt, s.descs.data(), &oi, &oo);
         bool in_direct = true;
         s.out_direct = masks != nullptr;
+        s.ov_direct = overlay != nullptr;
         for (int j = 0; j < cnt; ++j) {
             in_direct = in_direct && host_is_pinned(crops[first + j]);
             if (masks)
                 s.out_direct = s.out_direct && host_is_pinned(masks[first + j]);
+            if (overlay)
+                s.ov_direct = s.ov_direct && host_is_pinned(overlay->out_bgr[first + j]);
         }
         // uploads: page-locked crops are DMA'd in place, pageable ones are packed into the slot's pinned buffer by a few
         // threads (one core copies ~10 GB/s) and leave as one copy
@@ -595,7 +698,7 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
         if (nl == 1 && bi > 0)   // one workspace: this batch after the previous one (on the other stream)
             fail(hipStreamWaitEvent(compute, p.sl[(slot + NSLOT - 1) % NSLOT].done, 0), "hipStreamWaitEvent");
         gs_status st2 = run_batch(models, n_models, bi % nl, s.din, s.descs.data(), cnt, means, stds, net_h, net_w, s.dnet,
-                                  masks ? s.dout : nullptr, hist ? s.dh : nullptr, paste, compute);
+                                  (masks || overlay) ? s.dout : nullptr, hist ? s.dh : nullptr, paste, compute, overlay, overlay ? s.dov : nullptr);
         if (st2 != GS_OK) { rc = st2; break; }
         fail(hipEventRecord(s.done, compute), "hipEventRecord");
         // downloads through hipMemcpy2DAsync: the SDMA engine, not a blit kernel that would take CUs from the next forward
@@ -622,6 +725,25 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
                 }
             } else {
                 fail(hipMemcpy2DAsync(s.hout, oo, s.dout, oo, oo, 1, hipMemcpyDeviceToHost, compute), "D2H copy");
+            }
+        }
+        if (overlay) {
+            if (s.ov_direct) {   // (as the maps: one DMA for a batch laid out like the packed buffer inside ONE pinned allocation)
+                bool packed = true;
+                for (int j = 0; j < cnt; ++j)
+                    packed = packed && overlay->out_bgr[first + j] == overlay->out_bgr[first] + s.descs[j].in_off;
+                const size_t b = (size_t)s.descs[cnt - 1].in_off + (size_t)s.descs[cnt - 1].h * s.descs[cnt - 1].w * 3;
+                packed = packed && host_block_is_pinned(overlay->out_bgr[first], b);
+                if (packed) {
+                    fail(hipMemcpy2DAsync(overlay->out_bgr[first], b, s.dov, b, b, 1, hipMemcpyDeviceToHost, compute), "D2H copy");
+                } else {
+                    for (int j = 0; j < cnt && rc == GS_OK; ++j) {
+                        const size_t bj = (size_t)s.descs[j].h * s.descs[j].w * 3;
+                        fail(hipMemcpy2DAsync(overlay->out_bgr[first + j], bj, s.dov + s.descs[j].in_off, bj, bj, 1, hipMemcpyDeviceToHost, compute), "D2H copy");
+                    }
+                }
+            } else {
+                fail(hipMemcpy2DAsync(s.hov, oi, s.dov, oi, oi, 1, hipMemcpyDeviceToHost, compute), "D2H copy");
             }
         }
         if (net_masks)

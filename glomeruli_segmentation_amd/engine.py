@@ -316,20 +316,22 @@ def paste_target(slide_map, ds=8, luts=None):
 
 
 def segment_crops_host(engines, mean_stds, crops, net_h=512, net_w=1024, batch=32, want_masks=True, want_net_maps=False,
-                       want_hist=True, paste=None, origins=None):
+                       want_hist=True, paste=None, origins=None, overlay=None):
     """gs_espnet_segment_crops_host: crops of any sizes in host memory -> per-crop class maps at crop size.
 
     engines: one EspnetEngine (the plain model) or several (the cfg-5 ensemble, each with its own (mean, std) in mean_stds).
     crops: list of uint8 BGR [h,w,3] numpy arrays / CPU tensors (pinned ones are DMA'd in place).
     paste: an _lib.PasteTarget (see paste_target) + origins [(x1, y1), ...]: the crops are also max-composited into the
     slide map on the GPU.
+    overlay: (palette uint8 [k,3] RGB, wa, wb): also return every crop's class map coloured and blended over the crop,
+    cv2.addWeighted(crop, wa, colour, wb, 0) (VisualizeResults_iou.py:139-146), computed on the GPU for the whole batch.
     Returns dict(masks=list of uint8 [h,w] numpy views of one pinned buffer | None, net_maps=uint8 [n,net_h,net_w] | None,
-    counts=int64 [n,5] counts of the crop-size maps | None).
+    counts=int64 [n,classes] counts of the crop-size maps | None, overlays=list of uint8 [h,w,3] BGR views | None).
     """
     lib = _lib.load()
     n = len(crops)
     if n == 0:
-        return {"masks": [] if want_masks else None, "net_maps": None, "counts": None}
+        return {"masks": [] if want_masks else None, "net_maps": None, "counts": None, "overlays": [] if overlay is not None else None}
     keep = []      # keeps converted inputs alive for the duration of the call
     ptrs = (ctypes.c_void_p * n)()
     hs, ws = (ctypes.c_int * n)(), (ctypes.c_int * n)()
@@ -367,6 +369,20 @@ def segment_crops_host(engines, mean_stds, crops, net_h=512, net_w=1024, batch=3
             raise ValueError("paste needs one (x1, y1) level-0 origin per crop")
         x1 = (ctypes.c_int * n)(*[int(o[0]) for o in origins])
         y1 = (ctypes.c_int * n)(*[int(o[1]) for o in origins])
+    ov, ov_buf, ov_offs, pal = None, None, None, None
+    if overlay is not None:     # one pinned buffer laid out like the library's packed input: a batch's overlays leave in one DMA
+        palette, wa, wb = overlay
+        pal = np.ascontiguousarray(palette, dtype=np.uint8).reshape(-1, 3)
+        ov_offs = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([(int(hs[i]) * int(ws[i]) * 3 + 255) // 256 * 256 for i in range(n)], out=ov_offs[1:])
+        ov_buf = torch.empty(int(ov_offs[-1]), dtype=torch.uint8, pin_memory=True)
+        ov = _lib.CropOverlay()
+        ov.palette_rgb = pal.ctypes.data
+        ov.n_colours = int(pal.shape[0])
+        ov.wa, ov.wb = float(wa), float(wb)
+        ov_ptrs = (ctypes.c_void_p * n)(*[ov_buf.data_ptr() + int(ov_offs[i]) for i in range(n)])
+        ov.out_bgr = ctypes.cast(ov_ptrs, ctypes.POINTER(ctypes.c_void_p))
+        keep.append(ov_ptrs)
     for e in engines:
         e.quiesce()
     with torch.cuda.device(eng0.device):
@@ -374,13 +390,17 @@ def segment_crops_host(engines, mean_stds, crops, net_h=512, net_w=1024, batch=3
             handles, len(engines), ptrs, hs, ws, n, means, stds, net_h, net_w, batch, out_ptrs,
             ctypes.c_void_p(net.data_ptr()) if net is not None else None,
             ctypes.c_void_p(hist.data_ptr()) if hist is not None else None,
-            ctypes.byref(paste) if paste is not None else None, x1, y1))
+            ctypes.byref(paste) if paste is not None else None, x1, y1, ctypes.byref(ov) if ov is not None else None))
     masks = None
     if want_masks:
         flat = out_buf.numpy()
         masks = [flat[int(offs[i]):int(offs[i]) + int(hs[i]) * int(ws[i])].reshape(int(hs[i]), int(ws[i])) for i in range(n)]
+    overlays = None
+    if ov is not None:
+        flat = ov_buf.numpy()
+        overlays = [flat[int(ov_offs[i]):int(ov_offs[i]) + int(hs[i]) * int(ws[i]) * 3].reshape(int(hs[i]), int(ws[i]), 3) for i in range(n)]
     return {"masks": masks, "net_maps": net.numpy() if net is not None else None,
-            "counts": hist.numpy() if hist is not None else None}
+            "counts": hist.numpy() if hist is not None else None, "overlays": overlays}
 
 
 def ensemble_segment(engines, tiles_u8, mean_stds):

@@ -16,6 +16,8 @@ import io
 import json
 import os
 import sys
+import threading
+import time
 from argparse import ArgumentParser
 from collections import defaultdict
 
@@ -81,6 +83,29 @@ def metric_right(hist):
     return overall, per_acc, per_iu, np.nanmean(per_iu)
 
 
+OVERLAY_WEIGHTS = (0.4, 0.6)      # cv2.addWeighted(img_orig, 0.4, classMap_numpy_color, 0.6, 0), VisualizeResults_iou.py:145
+
+
+def segment_batch(engine, images, mean, std, width, height, batch, want_net_maps=False, want_overlay=False):
+    """What the loop body needs from the GPU for one batch of crops (:107-129, :139-146, :151-155), as a dict:
+    masks (crop-size class maps), net_maps (network-resolution maps | None), counts (int64 [n, classes]: pixels per class of the
+    crop-size maps) and overlays (the palette-coloured map blended over the crop, BGR | None) -- counts and overlays come out of
+    the batched crop pipeline with the maps (gs_espnet_segment_crops_host: crops_back_kernel counts, crops_overlay_kernel
+    blends), the host only encodes.  ESPNet-C (modelType 2) has no such pipeline: its maps come from segment_images and the
+    two by-products from the same arithmetic on the host."""
+    if engine.encoder_only or not images:
+        masks, net = segment_images(engine, images, mean, std, width, height, batch, want_net_maps=True)
+        counts = np.array([np.bincount(np.asarray(m).ravel(), minlength=engine.classes)[:engine.classes] for m in masks],
+                          dtype=np.int64).reshape(len(masks), engine.classes)
+        overlays = [imageops.add_weighted(im, OVERLAY_WEIGHTS[0], imageops.colourise(m), OVERLAY_WEIGHTS[1])
+                    for im, m in zip(images, masks)] if want_overlay else None
+        return {"masks": masks, "net_maps": net if want_net_maps else None, "counts": counts, "overlays": overlays}
+    r = engine.segment_crops(images, mean, std, height, width, batch, want_masks=True, want_net_maps=want_net_maps, want_hist=True,
+                             overlay=(imageops.PALETTE, OVERLAY_WEIGHTS[0], OVERLAY_WEIGHTS[1]) if want_overlay else None)
+    return {"masks": r["masks"], "net_maps": list(r["net_maps"]) if want_net_maps else None, "counts": r["counts"],
+            "overlays": r["overlays"]}
+
+
 def segment_images(engine, images, mean, std, width, height, batch, want_net_maps=False):
     """images: list of HxWx3 uint8 BGR crops of any size -> list of class maps at crop size
     (with want_net_maps: (crop-size maps, network-resolution maps) -- the reference scores the latter, :202).
@@ -137,7 +162,8 @@ def img_arr_to_b64(arr):
 def _load_crop(name, label_name):
     """decode stage (worker thread), one crop: the image as cv2.imread gives it (:103) and its label image (:191-192)"""
     from PIL import Image
-    return imageops.imread_bgr(name), (None if label_name is None else np.asarray(Image.open(label_name)))
+    with _timed("decode_png"):
+        return imageops.imread_bgr(name), (None if label_name is None else np.asarray(Image.open(label_name)))
 
 
 class _Done:
@@ -150,12 +176,33 @@ class _Done:
         return self.value
 
 
-def _emit_crop(args, img_name, label_name, img, cmap, net_map, lab, lab_r):
+def _timed(stage):
+    """per-stage host timing of _emit_crop / _load_crop for tools/bench_cli.py: STAGE_SECONDS[stage] accumulates thread seconds
+    when it is a dict, and costs one `is None` test otherwise"""
+    class _T:
+        def __enter__(self):
+            self.t0 = time.perf_counter() if STAGE_SECONDS is not None else 0.0
+
+        def __exit__(self, *exc):
+            if STAGE_SECONDS is not None:
+                dt = time.perf_counter() - self.t0
+                with _STAGE_LOCK:
+                    STAGE_SECONDS[stage] = STAGE_SECONDS.get(stage, 0.0) + dt
+            return False
+    return _T()
+
+
+STAGE_SECONDS = None          # tools/bench_cli.py sets a dict here to collect the breakdown
+_STAGE_LOCK = threading.Lock()
+
+
+def _emit_crop(args, img_name, label_name, img, cmap, net_map, lab, lab_r, counts, overlayed):
     """Everything the loop body writes for ONE crop after the forward (:131-231): overlay / original images, the counts row,
     the class map, the labelme JSON, with a label the per-image accuracy row and the combined image.  Host work only -- PNG /
     JPEG encoding, contour tracing, base64 -- and no state shared with other crops, so it runs on a worker thread while the
-    GPU is busy with the next batch.  Returns what the summary files need: (pixel row, accuracy row | None, (patient, label
-    values) | None, confusion matrix | None)."""
+    GPU is busy with the next batch.  `counts` (pixels per class of the crop-size map, :151-155) and `overlayed` (:139-146; None
+    when neither --colored nor a label asks for it) arrive from the GPU pass.  Returns what the summary files need: (pixel row,
+    accuracy row | None, (patient, label values) | None, confusion matrix | None)."""
     from PIL import Image
     from .contours import labelme_dict
     patient = os.path.basename(os.path.dirname(img_name))
@@ -163,25 +210,28 @@ def _emit_crop(args, img_name, label_name, img, cmap, net_map, lab, lab_r):
     stem = name.rsplit(".", 1)[0]
     odir = os.path.join(args.savedir, patient)
     os.makedirs(odir, exist_ok=True)
-    overlayed = None
-    if args.colored or label_name is not None:
-        colour = imageops.colourise(cmap)                                                  # :139-143
-        overlayed = imageops.add_weighted(img, 0.4, colour, 0.6)
-        if args.overlay:
-            imageops.imwrite_bgr(os.path.join(odir, stem + "_overlay.jpg"), overlayed)    # :145-148
+    if args.colored and args.overlay:                                                      # :139-148 (the blend itself: the GPU pass)
+        with _timed("overlay_jpeg"):
+            imageops.imwrite_bgr(os.path.join(odir, stem + "_overlay.jpg"), overlayed)
+        with _timed("org_png"):
             imageops.imwrite_bgr(os.path.join(odir, stem + "_org.png"), img)
-    counts = [int(np.count_nonzero(cmap == c)) for c in range(5)]                         # :151-155
-    row_pixel = "{},{},{},{},{},{},{}\n".format(patient, name.replace(args.img_extn, 'png'), *counts)
+    # :151-155: the reference's row names the five classes of its networks; a model with fewer has zeros there
+    c5 = [int(counts[c]) if c < len(counts) else 0 for c in range(5)]
+    row_pixel = "{},{},{},{},{},{},{}\n".format(patient, name.replace(args.img_extn, 'png'), *c5)
     out_map = imageops.relabel_city(cmap) if args.cityFormat else cmap                     # :158-159
     # The class map is always written beside the JSON (additive: the WSI compositor takes it from there); what the
     # JSON's imageData holds follows --imageData (the reference: the ORIGINAL crop, :179, although
     # eval_wsi_segmentation.py decodes it as a class map -- SURVEY quirks).
-    Image.fromarray(out_map).save(os.path.join(odir, stem + "_classmap.png"))
-    body = labelme_dict(out_map, name, stem + "_classmap.png")                             # :161-177
-    body["imageData"] = (img_arr_to_b64(img) if args.imageData == 'orig' else
-                         img_arr_to_b64(np.ascontiguousarray(out_map, dtype=np.uint8)) if args.imageData == 'classmap' else None)
-    with open(os.path.join(odir, name.replace(args.img_extn, 'json')), 'w') as f:
-        json.dump(body, f, indent=4)
+    with _timed("classmap_png"):
+        Image.fromarray(out_map).save(os.path.join(odir, stem + "_classmap.png"))
+    with _timed("contours"):
+        body = labelme_dict(out_map, name, stem + "_classmap.png")                         # :161-177
+    with _timed("base64_png"):
+        body["imageData"] = (img_arr_to_b64(img) if args.imageData == 'orig' else
+                             img_arr_to_b64(np.ascontiguousarray(out_map, dtype=np.uint8)) if args.imageData == 'classmap' else None)
+    with _timed("json"):
+        with open(os.path.join(odir, name.replace(args.img_extn, 'json')), 'w') as f:
+            json.dump(body, f, indent=4)
     if label_name is None:
         return row_pixel, None, None, None
     # the reference scores at network resolution (:195-203): the label is nearest-resized to the network size (lab_r, made on
@@ -257,7 +307,15 @@ def evaluate(args, engine, rgb_list, label_list, rank=0, world=1, dist=None):
             images, labels = [im for im, _ in loaded], [lb for _, lb in loaded]
             if bi + 1 < len(starts):      # decode ahead
                 nxt = load(starts[bi + 1])
-            masks, net_maps = segment_images(engine, images, mean, std, args.inWidth, args.inHeight, args.batch, want_net_maps=True)
+            want_overlay = bool(args.colored or any(l_ is not None for l_ in label_names))      # (:139, :215-231)
+            t_gpu = time.perf_counter()
+            r = segment_batch(engine, images, mean, std, args.inWidth, args.inHeight, args.batch, want_net_maps=True,
+                              want_overlay=want_overlay)
+            if STAGE_SECONDS is not None:
+                with _STAGE_LOCK:
+                    STAGE_SECONDS["gpu_pass"] = STAGE_SECONDS.get("gpu_pass", 0.0) + time.perf_counter() - t_gpu
+            masks, net_maps, counts = r["masks"], r["net_maps"], r["counts"]
+            overlays = r["overlays"] if want_overlay else [None] * len(images)
             labs_r = []
             for img_name, label_name, img, lab in zip(names, label_names, images, labels):
                 if label_name is None:
@@ -272,9 +330,10 @@ def evaluate(args, engine, rgb_list, label_list, rank=0, world=1, dist=None):
                     from .engine import mask_resize_nearest
                     labs_r.append(mask_resize_nearest(torch.from_numpy(np.array(lab, dtype=np.uint8)).to(engine.device),
                                                       args.inHeight, args.inWidth).cpu().numpy())      # :195 cv2.resize INTER_NEAREST
-            futs = [run(_emit_crop, args, n_, l_, im, np.array(cm), np.array(nm) if nm is not None else None, lb, lr)
-                    for n_, l_, im, cm, nm, lb, lr in zip(names, label_names, images, masks, net_maps, labels, labs_r)]
-            # (np.array: the maps are views of the pipeline's pinned output buffer, which the next call may reuse)
+            futs = [run(_emit_crop, args, n_, l_, im, np.array(cm), np.array(nm) if nm is not None else None, lb, lr,
+                        [int(v) for v in cn], None if ov is None else np.array(ov))
+                    for n_, l_, im, cm, nm, lb, lr, cn, ov in zip(names, label_names, images, masks, net_maps, labels, labs_r, counts, overlays)]
+            # (np.array: the maps and overlays are views of the pipeline's pinned output buffers, which the next call may reuse)
             pending.append(futs)
             if len(pending) > 2:          # write behind: at most two batches of outputs in flight
                 collect(pending.pop(0))

@@ -167,12 +167,26 @@ gs_status gs_espnet_ensemble_segment_crops(gs_espnet *const *models, int n_model
                                            uint8_t *packed_out, unsigned long long *hist, const gs_paste_target *paste,
                                            void *hip_stream);
 
+/* Optional overlay output of the host pipeline below (VisualizeResults_iou.py:139-146): every crop's class map coloured with the
+ * palette (rows RGB as in the reference's table, written [b, g, r]) and blended over the crop as
+ * cv2.addWeighted(crop, wa, colour, wb, 0) = saturate_cast<uchar>(round(crop * wa + colour * wb)), each product and the sum
+ * rounded to fp32 on its own (no fused multiply-add), round-half-to-even: bit for bit what numpy computes.  out_bgr[i] is host
+ * uint8 [heights[i], widths[i], 3]; page-locked buffers laid out like the packed input (every crop at the 256-byte-aligned
+ * offset behind its batch's first one, in ONE allocation) are written a batch per DMA, anything else crop by crop. */
+#define GS_MAX_PALETTE 64
+typedef struct gs_crop_overlay {
+    const uint8_t *palette_rgb; /* host, n_colours * 3 bytes; a class beyond the table is black */
+    int32_t n_colours;          /* 1 .. GS_MAX_PALETTE */
+    float wa, wb;
+    uint8_t *const *out_bgr;
+} gs_crop_overlay;
+
 /* Host-to-host pipeline over a list of crops of any sizes (the whole loop :100-156): crops[i] is uint8 BGR [heights[i],
  * widths[i],3] in host memory (page-locked buffers are DMA'd in place, pageable ones staged through pinned slots by a few
  * threads); up to `batch` (<= GS_MAX_CROPS_PER_CALL) crops per step; uploads on a stream of their own, batches alternate
  * between two compute streams (and two lanes when the handle has them), results come back by SDMA.  Outputs, each optional:
  * masks[i] (host uint8 [heights[i],widths[i]]), net_masks (host uint8 [n_crops,net_h,net_w]), hist (host uint64 [n_crops,classes],
- * counts of the crop-size maps), paste + x1/y1 (level-0 origins).  n_models == 1 is the plain model; > 1 the ensemble.
+ * counts of the crop-size maps), paste + x1/y1 (level-0 origins), overlay (above).  n_models == 1 is the plain model; > 1 the ensemble.
  * A list shorter than four full batches is cut into a small first batch (a seventh of the list, at least eight crops: its
  * upload is the pipeline's fill) and three equal ones.
  * Page-locked masks[] that lie in ONE block, every map in a 256-byte-aligned slot right behind the previous one, are
@@ -182,7 +196,8 @@ gs_status gs_espnet_ensemble_segment_crops(gs_espnet *const *models, int n_model
 gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, const uint8_t *const *crops, const int *heights,
                                        const int *widths, int n_crops, const float *means, const float *stds, int net_h,
                                        int net_w, int batch, uint8_t *const *masks, uint8_t *net_masks,
-                                       unsigned long long *hist, const gs_paste_target *paste, const int *x1, const int *y1);
+                                       unsigned long long *hist, const gs_paste_target *paste, const int *x1, const int *y1,
+                                       const gs_crop_overlay *overlay /* or NULL */);
 
 /* The batch plan gs_espnet_segment_crops_host follows, as a host-only function (no device work; csrc/crop_plan.h): batch b
  * holds crops [starts[b], starts[b+1]); *n_batches batches, starts gets *n_batches + 1 entries (cap counts ints; with

@@ -1527,3 +1527,35 @@ def test_other_class_counts_crops_ensemble_and_host_pipeline(torch_mod):
             EspnetEngine(random_state_dict(1, 1, classes=bad_c, seed=1), classes=bad_c, p=1, q=1)
     for e in engs + [e5]:
         e.close()
+
+
+def test_crop_pipeline_overlays_and_counts_equal_the_host_arithmetic(torch_mod, engine1):
+    """what the segment command line now takes from the GPU pass instead of recomputing it per crop on the host
+    (VisualizeResults_iou.py:139-146, :151-155): the palette-coloured class map blended over the crop is bit for bit
+    imageops.add_weighted(crop, 0.4, colourise(map), 0.6) (= cv2.addWeighted's saturate_cast<uchar>(round(.))), for crop sizes
+    whose pixel count is and is not a multiple of four, across batches; the counts are np.count_nonzero per class"""
+    from glomeruli_segmentation_amd import imageops
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, noise_tile
+    mean, std = FOLD_MEAN_STD[1]
+    sizes = CROP_SIZES + [(33, 35), (1, 7), (5, 1), (257, 129)]
+    crops = _crops(sizes, 1300)
+    crops[1] = noise_tile(9, *sizes[1])          # every byte value against every class colour
+    r = engine1.segment_crops(crops, mean, std, 64, 128, batch=4, overlay=(imageops.PALETTE, 0.4, 0.6))
+    plain = engine1.segment_crops(crops, mean, std, 64, 128, batch=4)
+    assert len(r["overlays"]) == len(crops) and plain["overlays"] is None
+    seen = set()
+    for c, m, m0, ov, cn in zip(crops, r["masks"], plain["masks"], r["overlays"], r["counts"]):
+        assert np.array_equal(m, m0)
+        assert ov.shape == c.shape and ov.dtype == np.uint8
+        assert np.array_equal(ov, imageops.add_weighted(c, 0.4, imageops.colourise(m), 0.6))
+        assert [int(v) for v in cn] == [int(np.count_nonzero(m == k)) for k in range(5)]
+        seen |= set(np.unique(m).tolist())
+    assert len(seen) >= 3
+    # other weights, a short palette (classes beyond it are black), pageable and pinned outputs give the same bytes
+    pal = imageops.PALETTE[:2]
+    r2 = engine1.segment_crops(crops[:3], mean, std, 64, 128, batch=2, overlay=(pal, 0.25, 0.75))
+    for c, m, ov in zip(crops, r2["masks"], r2["overlays"]):
+        colour = np.zeros(c.shape, np.uint8)
+        for k in range(2):
+            colour[m == k] = pal[k][::-1]
+        assert np.array_equal(ov, imageops.add_weighted(c, 0.25, colour, 0.75))

@@ -509,7 +509,7 @@ def test_cabi_argument_and_device_errors_without_gpu(sd1):
     assert lib.gs_crop_preprocess(None, 4, 4, None, None, 8, 8, None, None) == 1
     # the round-3 entries validate before they touch a device: null model list, bad network size, nothing to compute
     f3 = (ctypes.c_float * 3)(1.0, 1.0, 1.0)
-    assert lib.gs_espnet_segment_crops_host(None, 1, None, None, None, 1, f3, f3, 512, 1024, 32, None, None, None, None, None, None) == 1
+    assert lib.gs_espnet_segment_crops_host(None, 1, None, None, None, 1, f3, f3, 512, 1024, 32, None, None, None, None, None, None, None) == 1
     assert b"null" in lib.gs_last_error()
     assert lib.gs_espnet_segment_crops(None, 0, None, None, 1, f3, f3, 512, 1024, None, None, None, None, None) == 1
     assert lib.gs_espnet_ensemble_segment_crops(None, 0, None, None, 1, f3, f3, 512, 1024, None, None, None, None, None) == 1
