@@ -1535,22 +1535,25 @@ def test_crop_pipeline_overlays_and_counts_equal_the_host_arithmetic(torch_mod, 
     imageops.add_weighted(crop, 0.4, colourise(map), 0.6) (= cv2.addWeighted's saturate_cast<uchar>(round(.))), for crop sizes
     whose pixel count is and is not a multiple of four, across batches; the counts are np.count_nonzero per class"""
     from glomeruli_segmentation_amd import imageops
+    from glomeruli_segmentation_amd.engine import EspnetEngine
     from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, noise_tile
     mean, std = FOLD_MEAN_STD[1]
     sizes = CROP_SIZES + [(33, 35), (1, 7), (5, 1), (257, 129)]
-    crops = _crops(sizes, 1300)
-    crops[1] = noise_tile(9, *sizes[1])          # every byte value against every class colour
-    r = engine1.segment_crops(crops, mean, std, 64, 128, batch=4, overlay=(imageops.PALETTE, 0.4, 0.6))
-    plain = engine1.segment_crops(crops, mean, std, 64, 128, batch=4)
+    crops = [noise_tile(1300 + k, h, w) for k, (h, w) in enumerate(sizes)]      # every byte value ...
+    eng7 = EspnetEngine(random_state_dict(1, 2, classes=7, seed=77), classes=7, p=1, q=2)   # ... against many class colours
+    r = eng7.segment_crops(crops, (120.0, 130.0, 110.0), (60.0, 55.0, 70.0), 64, 128, batch=4, overlay=(imageops.PALETTE, 0.4, 0.6))
+    plain = eng7.segment_crops(crops, (120.0, 130.0, 110.0), (60.0, 55.0, 70.0), 64, 128, batch=4)
     assert len(r["overlays"]) == len(crops) and plain["overlays"] is None
     seen = set()
     for c, m, m0, ov, cn in zip(crops, r["masks"], plain["masks"], r["overlays"], r["counts"]):
         assert np.array_equal(m, m0)
         assert ov.shape == c.shape and ov.dtype == np.uint8
         assert np.array_equal(ov, imageops.add_weighted(c, 0.4, imageops.colourise(m), 0.6))
-        assert [int(v) for v in cn] == [int(np.count_nonzero(m == k)) for k in range(5)]
+        assert [int(v) for v in cn] == [int(np.count_nonzero(m == k)) for k in range(7)]
         seen |= set(np.unique(m).tolist())
-    assert len(seen) >= 3
+    assert len(seen) >= 4, seen
+    eng7.close()
+    crops = _crops(sizes, 1300)
     # other weights, a short palette (classes beyond it are black), pageable and pinned outputs give the same bytes
     pal = imageops.PALETTE[:2]
     r2 = engine1.segment_crops(crops[:3], mean, std, 64, 128, batch=2, overlay=(pal, 0.25, 0.75))

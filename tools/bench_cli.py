@@ -6,10 +6,12 @@ JSON (with the base64 crop) and summary_pixel.csv out, with the reference README
     python tools/bench_cli.py [--crops 448] [--out profiles/r04_cli_bench.json]
 
 448 crops of the example slide's 28 box sizes (mean 0.53 Mpx), written once as PNG under a scratch directory; the command is
-run with --workers 0 (the serial loop: decode, GPU, encode / trace / write one after the other, the reference's structure)
-and with the default worker pool (decode-ahead / write-behind while a batch is on the GPU).  The work is host-bound -- PNG
-decode and three PNG / JPEG encodes per crop against ~0.1 ms of GPU time -- so the figure scales with the cores the box
-gives the process; the core count is in the line."""
+run with --workers 0 (the serial loop: decode, GPU, encode / trace / write one after the other, the reference's structure),
+with the default worker pool (decode-ahead / write-behind while a batch is on the GPU) and with TWO workers on two CPUs -- a
+rank's share of the cores on an 8-GPU node.  The work is host-bound -- PNG decode and three PNG / JPEG encodes per crop against
+~0.1 ms of GPU time -- so the figure scales with the cores the process has; the core count is in the line.  The serial run also
+gives the per-stage breakdown of the host time (segment.STAGE_SECONDS): decode / GPU pass (counts and overlays included) /
+overlay JPEG / original PNG / class-map PNG / contours / base64 PNG / JSON."""
 import argparse
 import json
 import os
@@ -53,27 +55,42 @@ def main():
                   "--colored", "--overlay", "--cityFormat", "--mean"] + [str(v) for v in mean] + ["--std"] + [str(v) for v in std]
         res = {}
         cores = segment.default_workers()
-        for tag, workers in (("warmup", cores), ("serial", 0), ("overlapped", cores)):
+        allowed = sorted(os.sched_getaffinity(0))
+        stages = None
+        for tag, workers, cpus in (("warmup", cores, None), ("serial", 0, None), ("overlapped", cores, None), ("two_workers_two_cpus", 2, allowed[:2])):
             out = os.path.join(root, "out_" + tag)
+            if cpus is not None:
+                os.sched_setaffinity(0, cpus)
+            segment.STAGE_SECONDS = {} if tag == "serial" else None
             t0 = time.perf_counter()
             rc = segment.main(common + ["--savedir", out, "--workers", str(workers)])
             el = time.perf_counter() - t0
+            if cpus is not None:
+                os.sched_setaffinity(0, allowed)
             assert rc == 0
             n_files = sum(len(fs) for _, _, fs in os.walk(out))
-            res[tag] = {"workers": workers, "seconds": round(el, 3), "cli_crops_per_s": round(a.crops / el, 1), "files_written": n_files}
+            res[tag] = {"workers": workers, "cpus": len(cpus) if cpus is not None else len(allowed), "seconds": round(el, 3),
+                        "cli_crops_per_s": round(a.crops / el, 1), "files_written": n_files}
+            if tag == "serial":
+                stages = dict(segment.STAGE_SECONDS)
+                segment.STAGE_SECONDS = None
+                acc = sum(stages.values())
+                res[tag]["stage_ms_per_crop"] = {k: round(1e3 * v / a.crops, 2) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}
+                res[tag]["stage_ms_per_crop"]["(unaccounted: engine creation, weight load, CSV, thread hand-off)"] = round(1e3 * (el - acc) / a.crops, 2)
             print(tag, res[tag], flush=True)
         same = True
         import filecmp
         for d, _, fs in os.walk(os.path.join(root, "out_serial")):
             for f in fs:
                 p1 = os.path.join(d, f)
-                p2 = p1.replace("out_serial", "out_overlapped")
-                same = same and os.path.isfile(p2) and filecmp.cmp(p1, p2, shallow=False)
+                for other in ("out_overlapped", "out_two_workers_two_cpus"):
+                    p2 = p1.replace("out_serial", other)
+                    same = same and os.path.isfile(p2) and filecmp.cmp(p1, p2, shallow=False)
         line = {"what": "python -m glomeruli_segmentation_amd.segment end to end (engine creation included), %d PNG crops of the example "
                         "slide's sizes -> overlay jpg + org png + class map png + labelme json (base64 crop) + summary_pixel.csv; "
                         "--colored --overlay --cityFormat --decoder" % a.crops,
                 "crops": a.crops, "host_cores_of_the_process": cores, "mean_crop_px": int(np.mean([c.shape[0] * c.shape[1] for c in base])),
-                "serial": res["serial"], "overlapped": res["overlapped"],
+                "serial": res["serial"], "overlapped": res["overlapped"], "two_workers_two_cpus": res["two_workers_two_cpus"],
                 "speedup": round(res["serial"]["seconds"] / res["overlapped"]["seconds"], 2),
                 "outputs_identical_byte_for_byte": bool(same), "png_generation_s": round(t_gen, 2)}
         print(json.dumps(line))
