@@ -110,32 +110,75 @@ def host_cores():
     return cores
 
 
+def _cgroup_cpu():
+    """what the kernel says about this process's CPU share: the cgroup quota and its throttling counters"""
+    out = {}
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        out["cpu_max"] = "%s %s" % (quota, period)
+    except (OSError, ValueError):
+        out["cpu_max"] = None
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as f:
+            st = dict(line.split() for line in f if len(line.split()) == 2)
+        for k in ("nr_periods", "nr_throttled", "throttled_usec"):
+            if k in st:
+                out[k] = int(st[k])
+    except OSError:
+        pass
+    return out
+
+
 def cpu_baseline(sd, tiles, mean, std):
-    """The torch-operator port of the reference graph on this box's host cores; bounded sample."""
+    """The torch-operator port of the reference graph on this box's host cores; bounded sample.
+
+    `value` is bound to BATCH 1 -- the batch size of the reference's own loop (VisualizeResults_iou.py:119-123: one crop per
+    `model(img_variable)`) -- with batch 4 beside it, each as 3 warm-up + 10 timed forwards.  The line also
+    carries what is needed to read the two figures against each other: torch's thread count, the affinity mask, the cgroup CPU
+    quota, every iteration's time and the cgroup's throttling counters over each leg (a process whose OpenMP team spins on
+    more runnable threads than its quota pays for them in throttled periods; the batch-4 forward holds its team ~4x longer
+    per call)."""
     import torch
     from oracle import espnet_torch_port as port   # bench's cpu_baseline leg only
     tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
     cores = host_cores()
     torch.set_num_threads(cores)
-    def run(bs, budget_s, max_reps):
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
+
+    def run(bs, warm=3, timed=10):
         x = port.preprocess(tiles[:bs], mean, std)
-        port.espnet_forward(x, tsd)                      # warm-up
-        t0 = time.perf_counter()
-        reps = 0
-        while True:
+        for _ in range(warm):
             port.espnet_forward(x, tsd)
-            reps += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or reps >= max_reps:
-                break
-        return bs * reps / el, reps
-    # batch 4 (the better CPU figure) and batch 1 (what the reference's loop runs, VisualizeResults_iou.py:119-123), BASELINE.md 4
-    v4, r4 = run(4, 10.0, 40)
-    v1, r1 = run(1, 6.0, 40)
-    return {"value": round(v4, 3), "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": "%d x batch-4 forward of the 1024x512 workload through torch CPU ops (oracle/espnet_torch_port.py)" % r4,
-            "batch1": {"value": round(v1, 3), "unit": "patches/s",
-                       "sample": "%d x batch-1 forward, the batch size of the reference's own loop" % r1}}
+        c0 = _cgroup_cpu()
+        its = []
+        for _ in range(timed):
+            t0 = time.perf_counter()
+            port.espnet_forward(x, tsd)
+            its.append(time.perf_counter() - t0)
+        c1 = _cgroup_cpu()
+        leg = {"value": round(bs * timed / sum(its), 3), "unit": "patches/s", "batch": bs,
+               "iteration_ms": [round(1e3 * t, 1) for t in its],
+               "sample": "%d warm-up + %d timed batch-%d forwards of the 1024x512 workload through torch CPU ops "
+                         "(oracle/espnet_torch_port.py)" % (warm, timed, bs)}
+        for k in ("nr_periods", "nr_throttled", "throttled_usec"):
+            if k in c0 and k in c1:
+                leg["cgroup_" + k] = c1[k] - c0[k]
+        return leg
+
+    b1 = run(1)     # what the reference's loop runs
+    b4 = run(4)
+    out = {"value": b1["value"], "unit": "patches/s", "cores": cores, "kind": "port", "batch": 1, "sample": b1["sample"],
+           "iteration_ms": b1["iteration_ms"], "torch_num_threads": torch.get_num_threads(), "affinity_cpus": affinity,
+           "cgroup_cpu_max": _cgroup_cpu().get("cpu_max"), "batch4": b4,
+           "note": "value = batch 1, the batch size of the reference's own loop; batch 4 beside it (BASELINE.md 4)"}
+    for k in ("cgroup_nr_periods", "cgroup_nr_throttled", "cgroup_throttled_usec"):
+        if k in b1:
+            out[k] = b1[k]
+    return out
 
 
 def parity_vs_golden(mask_np):

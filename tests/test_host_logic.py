@@ -974,3 +974,194 @@ def test_crop_batch_plan_never_exceeds_the_callers_batch():
     nb = ctypes.c_int(0)
     assert lib.gs_plan_crop_batches((ctypes.c_int * 1)(0), (ctypes.c_int * 1)(5), 1, 4, None, 0, ctypes.byref(nb)) != 0   # bad size
     assert lib.gs_host_block_is_pinned(None, 10) == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Eight-rank rehearsals on the CPU (gloo): the rank-count-dependent control flow of everything the driver will start with
+# `--gpus 8` -- spawn, rendezvous, uneven and empty ranges, gathers / reductions, one rank failing, CPU placement -- so that the
+# first real eight-GPU run cannot die on arithmetic that only shows with more than two ranks.  No scaling is simulated.
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(OMP_NUM_THREADS="1", **extra)
+    return env
+
+
+def _last_json(text):
+    import json
+    return json.loads([l for l in text.strip().splitlines() if l.startswith("{")][-1])
+
+
+def test_eight_ranks_bench_dry_run_and_one_rank_failing():
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = _last_json(p.stdout)
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and len(j["per_rank_ms_per_step"]) == 8
+    assert j["config"]["parallelism"] == "tile-range per rank x8" and j["config"]["global_batch"] == 8 * 32
+    assert j["pixel_totals_all_ranks"] == [8 * 3] * 5              # the dry engine counts one per class per step: all 8 ranks reduced
+    assert len(j["host_pipeline"]["per_rank_patches_per_s"]) == 8
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run",
+                        "--fail-rank", "5"], env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 3 and time.time() - t0 < 120 and "rank 5 of 8 exited with code 3" in p.stderr, (p.returncode, p.stderr[-1500:])
+
+
+def test_eight_ranks_slide_bench_equals_one_rank():
+    """cfg 4's tool with CPU stand-ins: 36 windows and 56 crops over 8 ranks (4 / 5 windows, 7 crops per rank) give the slide map
+    and the class totals of one rank; with a slide of four windows some ranks' ranges are EMPTY"""
+    tool = os.path.join(REPO, "tools", "bench_slide.py")
+    out = {}
+    for size, gpus in ((40000, 1), (40000, 8), (12000, 1), (12000, 8)):
+        p = subprocess.run([sys.executable, tool, "--dry-run", "--size", str(size), "--gpus", str(gpus)], env=_clean_env(),
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[size, gpus] = _last_json(p.stdout)
+    j1, j8 = out[40000, 1], out[40000, 8]
+    assert j8["windows"] == 36 and j8["crops"] == 56
+    assert [b - a for a, b in j8["window_ranges"]] == [4, 5, 4, 5, 4, 5, 4, 5] and j8["window_ranges"][-1][1] == 36
+    assert [b - a for a, b in j8["crop_ranges"]] == [7] * 8
+    assert j8["pixel_totals"] == j1["pixel_totals"] and j8["map_nonzero"] == j1["map_nonzero"] and sum(j1["pixel_totals"]) > 0
+    s1, s8 = out[12000, 1], out[12000, 8]
+    assert s8["windows"] < 8 and any(a == b for a, b in s8["window_ranges"])                 # ranks without a window
+    assert sum(b - a for a, b in s8["window_ranges"]) == s8["windows"] and sum(b - a for a, b in s8["crop_ranges"]) == s8["crops"]
+    assert s8["pixel_totals"] == s1["pixel_totals"] and s8["map_nonzero"] == s1["map_nonzero"]
+
+
+def test_eight_ranks_ensemble_bench_equals_one_rank():
+    """cfg 5's tool with CPU stand-ins: 8 slides over 8 ranks (one each) and 3 slides over 8 ranks (five ranks with nothing to
+    do) give one rank's per-slide totals"""
+    tool = os.path.join(REPO, "tools", "bench_ensemble.py")
+    out = {}
+    for slides, gpus in ((8, 8), (3, 8), (8, 1)):
+        p = subprocess.run([sys.executable, tool, "--dry-run", "--size", "12000", "--slides", str(slides), "--gpus", str(gpus)],
+                           env=_clean_env(), capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[slides, gpus] = _last_json(p.stdout)
+    assert out[8, 8]["pixel_totals_per_slide"] == out[8, 1]["pixel_totals_per_slide"] and len(out[8, 8]["pixel_totals_per_slide"]) == 8
+    assert out[3, 8]["pixel_totals_per_slide"] == out[8, 1]["pixel_totals_per_slide"][:3]
+    assert all(sum(row) > 0 for row in out[8, 8]["pixel_totals_per_slide"])
+
+
+def _spawn_env():
+    saved = {k: os.environ.get(k) for k in ("GLOMSEG_DIST_BACKEND", "GS_TEST_FAIL_RANK", "MASTER_PORT", "WORLD_SIZE", "RANK", "LOCAL_RANK",
+                                            "OMP_NUM_THREADS")}
+    for k in ("MASTER_PORT", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    os.environ["GLOMSEG_DIST_BACKEND"] = "gloo"
+    os.environ["OMP_NUM_THREADS"] = "1"
+    return saved
+
+
+def _restore_env(saved):
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def test_eight_ranks_segment_cli_writes_one_set_of_files(tmp_path):
+    """the segment command line's sharding, gathers and file writing as 8 gloo ranks with a CPU stand-in for the engine: 56 crops
+    (7 per rank) and 5 crops (three ranks with an empty range) write byte for byte the files of one process; one rank failing
+    alone ends the job"""
+    import filecmp
+    import io
+    from PIL import Image
+    from glomeruli_segmentation_amd import launch
+    from glomeruli_segmentation_amd.synth import synth_tile
+    helper = os.path.join(REPO, "tests", "helpers", "segment_stub_rank.py")
+    saved = _spawn_env()
+    try:
+        for n in (56, 5):
+            rgb = tmp_path / ("rgb%d" % n)
+            for k in range(n):
+                d = rgb / ("P%d" % (k % 3))
+                d.mkdir(parents=True, exist_ok=True)
+                Image.fromarray(np.ascontiguousarray(synth_tile(k, 24 + k % 5, 40 + k % 7, blobs=2)[:, :, ::-1])).save(d / ("xmin%d_ymin0_xmax9_ymax9.PNG" % k))
+            argv = ["--rgb_data_dir", str(rgb), "--weights", "unused", "--mean", "1", "2", "3", "--std", "1", "2", "3", "--inWidth", "64",
+                    "--inHeight", "32", "--batch", "4", "--colored", "--overlay", "--cityFormat", "--workers", "1"]
+            os.environ["GS_TEST_FAIL_RANK"] = "none"
+            os.environ.pop("MASTER_PORT", None)
+            out8, err8 = io.StringIO(), io.StringIO()
+            assert launch.spawn_ranks(helper, argv + ["--savedir", str(tmp_path / ("out8_%d" % n))], 8, out=out8, err=err8) == 0, err8.getvalue()[-2000:]
+            p = subprocess.run([sys.executable, helper] + argv + ["--savedir", str(tmp_path / ("out1_%d" % n))], env=_clean_env(),
+                               capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-2000:]
+            a, b = tmp_path / ("out1_%d" % n), tmp_path / ("out8_%d" % n)
+            fa = sorted(os.path.relpath(os.path.join(d, f), a) for d, _, fs in os.walk(a) for f in fs)
+            fb = sorted(os.path.relpath(os.path.join(d, f), b) for d, _, fs in os.walk(b) for f in fs)
+            assert fa == fb and len(fa) >= 4 * n + 1
+            assert all(filecmp.cmp(a / f, b / f, shallow=False) for f in fa)
+            assert len(open(b / "summary_pixel.csv").read().splitlines()) == n + 1
+        os.environ["GS_TEST_FAIL_RANK"] = "6"
+        os.environ.pop("MASTER_PORT", None)
+        err = io.StringIO()
+        rc = launch.spawn_ranks(helper, argv + ["--savedir", str(tmp_path / "out_fail")], 8, out=io.StringIO(), err=err)
+        assert rc == 1 and "rank 6 of 8 exited with code 1" in err.getvalue() and "fails on purpose" in err.getvalue()
+    finally:
+        _restore_env(saved)
+
+
+def test_eight_ranks_detect_cli_equals_one_process(tmp_path):
+    """the detect command line with the stub detector as 8 gloo ranks: 21 windows (2 / 3 per rank) write the CSV of one process,
+    row for row; rank 3 failing alone ends the job at once"""
+    import io
+    import time
+    from glomeruli_segmentation_amd import launch
+    data_dir, tl, _ = _png_slide_tree(tmp_path)
+    helper = os.path.join(REPO, "tests", "helpers", "detect_stub_rank.py")
+    argv = ["--target_list", tl, "--data_dir", data_dir, "--staining", "OPT_PAS", "--window_size", "2000", "--overlap_ratio", "0.1", "--batch", "2"]
+    saved = _spawn_env()
+    try:
+        os.environ["GS_TEST_FAIL_RANK"] = "none"
+        err = io.StringIO()
+        assert launch.spawn_ranks(helper, argv + ["--output_dir", str(tmp_path / "out8")], 8, out=io.StringIO(), err=err) == 0, err.getvalue()[-2000:]
+        p = subprocess.run([sys.executable, helper] + argv + ["--output_dir", str(tmp_path / "out1")], env=_clean_env(GS_TEST_FAIL_RANK="none"),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+
+        def rows(d):      # (field 4 is the wall-clock time of the row)
+            return [r.split(",")[:4] + r.split(",")[5:] for r in open(d / "OPT_PAS_GlomusList.csv").read().splitlines()]
+        assert rows(tmp_path / "out8") == rows(tmp_path / "out1") and len(rows(tmp_path / "out8")) == 21
+        os.environ["GS_TEST_FAIL_RANK"] = "3"
+        os.environ.pop("MASTER_PORT", None)
+        t0 = time.time()
+        err = io.StringIO()
+        rc = launch.spawn_ranks(helper, argv + ["--output_dir", str(tmp_path / "outf")], 8, out=io.StringIO(), err=err)
+        assert rc == 1 and time.time() - t0 < 120 and "rank 3 of 8 exited with code 1" in err.getvalue()
+    finally:
+        _restore_env(saved)
+
+
+def test_eight_ranks_split_sixteen_cpus(tmp_path):
+    """launch.rank_cpus with eight ranks: 16 allowed CPUs and no topology -> two each, disjoint, all used; eight GPUs on two
+    NUMA nodes of a fake sysfs -> every rank gets a quarter of its node's allowed CPUs; fewer CPUs than ranks still gives every
+    rank something to run on"""
+    from glomeruli_segmentation_amd import launch
+    got = [launch.rank_cpus(r, 8, set(range(16)), str(tmp_path / "none"), {}) for r in range(8)]
+    assert got == [[2 * r, 2 * r + 1] for r in range(8)]
+    sysfs = tmp_path / "sys"
+    nodes = sysfs / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    (nodes / "0").mkdir(parents=True)
+    (nodes / "0" / "properties").write_text("cpu_cores_count 64\nsimd_count 0\n")
+    for k in range(8):
+        bus, numa = 0x05 + 0x10 * k, k // 4
+        d = nodes / str(k + 1)
+        d.mkdir()
+        d.joinpath("properties").write_text("simd_count 1024\nlocation_id %d\ndomain 0\n" % (bus << 8))
+        pci = sysfs / "bus" / "pci" / "devices" / ("0000:%02x:00.0" % bus)
+        pci.mkdir(parents=True)
+        pci.joinpath("numa_node").write_text("%d\n" % numa)
+    for n, cl in ((0, "0-31"), (1, "32-63")):
+        d = sysfs / "devices" / "system" / "node" / ("node%d" % n)
+        d.mkdir(parents=True)
+        d.joinpath("cpulist").write_text(cl + "\n")
+    got = [launch.rank_cpus(r, 8, set(range(64)), str(sysfs), {}) for r in range(8)]
+    assert [len(g) for g in got] == [8] * 8 and sorted(c for g in got for c in g) == list(range(64))
+    assert all(max(g) < 32 for g in got[:4]) and all(min(g) >= 32 for g in got[4:])
+    # a cgroup of 16 CPUs, all on node 0: ranks of node 0 share them, ranks of node 1 (no allowed CPU there) still get some
+    got = [launch.rank_cpus(r, 8, set(range(16)), str(sysfs), {}) for r in range(8)]
+    assert all(len(g) >= 1 for g in got) and all(set(g) <= set(range(16)) for g in got)
+    got = [launch.rank_cpus(r, 8, {0, 1, 2}, str(tmp_path / "none"), {}) for r in range(8)]
+    assert all(len(g) >= 1 and set(g) <= {0, 1, 2} for g in got)

@@ -37,26 +37,39 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--slides", type=int, default=8)
     ap.add_argument("--size", type=int, default=40000)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="control flow only with CPU stand-ins over gloo (tools/dry.py): the CPU test suite's 8-rank rehearsal; never a measurement")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn(args)
 
     import numpy as np
     import torch
-    from glomeruli_segmentation_amd.composite import SlideCompositor
-    from glomeruli_segmentation_amd.engine import EspnetEngine, segment_crops_host
     from glomeruli_segmentation_amd.launch import place_rank
     from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD
 
     place_rank()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = 0 if os.environ.get("GS_BENCH_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
-    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dry = args.dry_run
+    backend = "gloo" if dry else os.environ.get("GS_BENCH_BACKEND", "nccl")
+    if dry:
+        import dry as stand_ins          # tools/dry.py (this directory is on sys.path: bench_slide is imported from it)
+        SlideCompositor, segment_crops_host = stand_ins.DryCompositor, stand_ins.dry_segment_crops_host
+        dev = torch.device("cpu")
+    else:
+        from glomeruli_segmentation_amd.composite import SlideCompositor
+        from glomeruli_segmentation_amd.engine import EspnetEngine, segment_crops_host
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
     dist = None
     if world > 1:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -73,6 +86,9 @@ def main():
     folds = [1, 2, 3, 4, 5]
     engines = []
     for f in folds:
+        if dry:
+            engines.append(stand_ins.DryEngine())
+            continue
         z = np.load(os.path.join(REPO, "tests", "golden", "weights_fold%d.npz" % f))
         engines.append(EspnetEngine({k: z[k] for k in z.files}, lanes=2))
     mean_stds = [FOLD_MEAN_STD[f] for f in folds]
@@ -84,7 +100,7 @@ def main():
     t_read = t_gpu = 0.0
     n_crops = 0
     origins = [(b[0], b[1]) for b in boxes]
-    torch.cuda.synchronize()
+    sync()
     t_start = time.perf_counter()
     warm = False
     for sid in mine:
@@ -99,7 +115,7 @@ def main():
         comp = SlideCompositor(S, S, dev)
         r = segment_crops_host(engines, mean_stds, crops, NH, NW, B, want_masks=True, paste=comp.paste_target(), origins=origins)
         totals[sid] += torch.from_numpy(r["counts"].sum(0)).to(dev)
-        torch.cuda.synchronize()
+        sync()
         t_gpu += time.perf_counter() - t0
         n_crops += len(boxes)
     t_total = time.perf_counter() - t_start
@@ -117,6 +133,7 @@ def main():
         crops_all = len(boxes) * args.slides
         print(json.dumps({
             "config": "cfg 5: five-fold ensemble over %d synthetic %d x %d slides, one slide per rank, %d rank(s)" % (args.slides, S, S, world),
+            "data": "dry-run (CPU stand-ins, no device work)" if dry else "synthetic",
             "slides": args.slides, "crops_per_slide": len(boxes), "folds": len(folds),
             "gpu_leg_s": round(t_gpu_m, 3), "slides_per_s": round(args.slides / t_gpu_m, 2),
             "crops_per_s": round(crops_all / t_gpu_m, 1), "model_passes_per_s": round(crops_all * len(folds) / t_gpu_m, 1),

@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--size", type=int, default=40000)
     ap.add_argument("--detector-batch", type=int, default=12, help="windows per detector forward (36 windows = 3 x 12: no ragged last batch)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="control flow only (spawn, rank ranges, reductions, JSON) with CPU stand-ins for the engine, the detector and "
+                         "the compositor over gloo (tools/dry.py): what the CPU test suite runs with 8 ranks; never a measurement")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn(args)
@@ -94,9 +97,6 @@ def main():
     import numpy as np
     import torch
     from glomeruli_segmentation_amd import detect, merge
-    from glomeruli_segmentation_amd.composite import SlideCompositor
-    from glomeruli_segmentation_amd.detector import FrcnnDetector, synthetic_weights
-    from glomeruli_segmentation_amd.engine import EspnetEngine
     from glomeruli_segmentation_amd.pipeline import segment_crops
     from glomeruli_segmentation_amd.shard import rank_range
     from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD
@@ -105,19 +105,34 @@ def main():
     place_rank()           # CPU share of this rank's GPU, before the first GPU call
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = 0 if os.environ.get("GS_BENCH_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
-    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dry = args.dry_run
+    backend = "gloo" if dry else os.environ.get("GS_BENCH_BACKEND", "nccl")
+    if dry:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import dry as stand_ins
+        SlideCompositor = stand_ins.DryCompositor
+        dev = torch.device("cpu")
+    else:
+        from glomeruli_segmentation_amd.composite import SlideCompositor
+        from glomeruli_segmentation_amd.detector import FrcnnDetector, synthetic_weights
+        from glomeruli_segmentation_amd.engine import EspnetEngine
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     from glomeruli_segmentation_amd.shard import all_reduce_any, log_device_order
-    if world > 1 and os.environ.get("GS_BENCH_ONE_GPU") != "1":
+    if world > 1 and os.environ.get("GS_BENCH_ONE_GPU") != "1" and not dry:
         log_device_order(local)
 
     def all_reduce(t, op=None):
@@ -128,9 +143,12 @@ def main():
     boxes_all = grid_boxes(S, example)
     slide = SynthSlide(S, S, boxes_all)
     mean, std = FOLD_MEAN_STD[1]
-    z = np.load(os.path.join(REPO, "tests", "golden", "weights_fold1.npz"))
-    eng = EspnetEngine({k: z[k] for k in z.files}, lanes=2)
-    det = FrcnnDetector(synthetic_weights(0))
+    if dry:
+        eng, det = stand_ins.DryEngine(), stand_ins.DryDetector()
+    else:
+        z = np.load(os.path.join(REPO, "tests", "golden", "weights_fold1.npz"))
+        eng = EspnetEngine({k: z[k] for k in z.files}, lanes=2)
+        det = FrcnnDetector(synthetic_weights(0))
     t_start = time.perf_counter()
 
     # ---- the slide's regions, generated once (the generator stands in for OpenSlide and is CPU numpy)
@@ -162,7 +180,7 @@ def main():
         if dist is not None:
             all_reduce(counts)
             all_reduce(comp.map, op=dist.ReduceOp.MAX)        # the one exchange: max-composite is associative
-        torch.cuda.synchronize()
+        sync()
         return comp, counts
 
     # first pass: allocates the workspaces and the pinned staging buffers (once per process, not once per slide)
@@ -177,7 +195,7 @@ def main():
     for _ in range(3):
         t0 = time.perf_counter()
         rows = detect_leg()
-        torch.cuda.synchronize()
+        sync()
         t_det.append(time.perf_counter() - t0)
         dets = [[float(v) for v in r.strip().split(",")[5:10]] for r in rows]
         merged_det = merge.merge_detections(dets, mpp, mpp, 0.35, 0.2) if dets else []
@@ -202,9 +220,16 @@ def main():
         return float(t.item())
     t_detect_m, t_seg_m, t_read_m, t_total_m, t_first_m = mx(t_detect), mx(t_seg), mx(t_read), mx(t_total), mx(t_first)
     t_seg_b2b_m = mx(t_seg_b2b)
+    # every rank's ranges, for the record (and for the rehearsal tests: uneven and empty ranges must add up)
+    ranges = torch.zeros((world, 4), dtype=torch.int64, device=dev)
+    ranges[rank] = torch.tensor([lo, hi, blo, bhi], dtype=torch.int64)
+    if dist is not None:
+        all_reduce(ranges)
     if rank == 0:
         print(json.dumps({
             "config": "cfg 4: detect -> merge -> crop -> segment -> composite, one synthetic %d x %d slide, %d rank(s)" % (S, S, world),
+            "data": "dry-run (CPU stand-ins, no device work)" if dry else "synthetic",
+            "window_ranges": [[int(a), int(b)] for a, b, _, _ in ranges.tolist()], "crop_ranges": [[int(c), int(d)] for _, _, c, d in ranges.tolist()],
             "windows": len(wins), "window_px": [plan.window_y, plan.window_x], "crops": len(boxes_all),
             "detect_leg_s": round(t_detect_m, 4), "windows_per_s": round(len(wins) / t_detect_m, 1),
             "segment_composite_leg_s": round(t_seg_m, 4), "segment_composite_leg_back_to_back_s": round(t_seg_b2b_m, 4), "crops_per_s": round(len(boxes_all) / t_seg_m, 1),
