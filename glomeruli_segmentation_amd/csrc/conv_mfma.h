@@ -23,6 +23,7 @@
 #pragma once
 #include <map>
 #include <mutex>
+#include <type_traits>
 
 #include "gs_internal.h"
 
@@ -35,6 +36,16 @@ constexpr bool kDiag = true;
 #else
 constexpr bool kDiag = false;
 #endif
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in that order, every index a compile-time constant
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -215,6 +226,11 @@ constexpr int F_S2_FLIP = 1048576;
 // (G == NSTEP) such a chunk is skipped (wave-uniform), and the operand ring is refilled with the next LIVE chunk instead.
 constexpr int F_SKIP_PAD = 4194304;
 constexpr int F_BNLOAD = 8388608;  // see ConvArgs::bnl_s0
+// Branch kernels whose chunk is a whole dilation (level 2): the epilogue of concat slot d -- residual add, BN, PReLU, stores, the
+// fused 1x1's matrix instructions -- is not run in one piece between two dilations (a stretch in which this wave feeds the matrix
+// pipe nothing) but register by register BETWEEN the k-steps of dilation d + 1, from a snapshot of the accumulator (HFF keeps
+// adding into the accumulator itself).  The last slot of a task still runs in one piece.
+constexpr int F_EPI_PIPE = 16777216;
 constexpr int F_X_NOLOAD = 16;  // GS_DIAG timing experiments only (results are garbage): no activation loads in the loop
 constexpr int F_X_NOLDS = 32;   // GS_DIAG: no LDS weight reads in the loop
 constexpr int F_X_NOEPI = 64;   // GS_DIAG: no epilogue at all
@@ -275,6 +291,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
     constexpr bool S2FLIP = FLAGS & F_S2_FLIP;
     constexpr bool SKIP = FLAGS & F_SKIP_PAD;
     constexpr bool BNL = FLAGS & F_BNLOAD;
+    constexpr bool EPI_PIPED = FLAGS & F_EPI_PIPE;
     static_assert(!BNL || ((FLAGS & F_S2PAIR) && !(FLAGS & (F_BNACT | F_A_GLOBAL | F_VEC))), "F_BNLOAD is for the plain stride-2 reduce");
     static_assert(!SKIP || (TAPS == 9 && STRIDE == 1 && !(FLAGS & (F_S2PAIR | F_XMERGE)) && G * M_KL_OF(MT) == CINP),
                   "F_SKIP_PAD: unit-stride 3x3 with one tap row per chunk");
@@ -308,6 +325,8 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
     static_assert(CINP % KL == 0, "k-steps must tile");
     static_assert(TAPS == 1 || TAPS == 9 || (TAPS == 3 && XMERGE && NDIL == 1 && STRIDE == 1 && 3 * NOUT1 <= MT), "1x1, 3x3 or row-merged 3x3");
     static_assert(RGN % G == 0, "chunk must divide the row groups of one dilation");
+    static_assert(!EPI_PIPED || (CPD == 1 && NDIL > 1 && TAPS == 9 && (FLAGS & F_BNACT) && !(FLAGS & (F_XMERGE | F_SKIP_PAD | F_RES_RING)) && D >= 4 * Mfma<MT>::NACC),
+                  "F_EPI_PIPE: branch kernels whose chunk is one dilation, with a k-step to spare per accumulator register");
     static_assert(NROW <= MT, "one MFMA row block");
     constexpr int KSTR = 4;   // accumulator rows of k-group kq sit KSTR*kq above those of group 0 (both shapes)
 
@@ -681,6 +700,75 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                 __builtin_amdgcn_s_setprio(1);
         }
 
+        // One accumulator register (channel row r of both k-groups) of concat slot di on its way out: + residual, BN, PReLU,
+        // store(s), the fused 1x1's matrix instructions.  `src` is the accumulator itself or (F_EPI_PIPE) its snapshot.
+        auto epi_reg = [&](int di, auto r_, const typename M::acc_t *src, bool refill_next) __attribute__((always_inline)) {
+            constexpr int r = decltype(r_)::value;
+            const int nout = di == 0 ? NOUT1 : NOUT;
+            const int cb = di == 0 ? 0 : NOUT1 + (di - 1) * NOUT;
+            const int ch0 = M::row(r, 0);   // channel held by k-group 0; group kq holds ch0 + kq*KSTR
+            const bool live = ch0 + kq * KSTR < nout;
+            // (read at the top of the register's step, not inside the uniform branch around its MFMAs: the LDS
+            // latency then runs under the BN / PReLU arithmetic instead of in front of the matrix instructions)
+            const float a2 = FUSE ? tab[(di * M::NACC + r) * 64 + lane] : 0.0f;
+            const int so = (cb + ch0) * a.out_sc * 4 + sout;
+            const int so2 = DUAL ? (a.out2_coff + cb + ch0) * a.out2_sc * 4 + sout2 : 0;
+            float scale = 1.0f, shift = 0.0f, alpha = 1.0f, scale2 = 1.0f, shift2 = 0.0f, alpha2 = 1.0f;
+            if (BNACT) {
+                const float *bp = bnp + (live ? cb + ch0 + kq * KSTR : 0);
+                scale = bp[0];
+                shift = bp[COUT];
+                alpha = bp[2 * COUT];
+                if (DUAL) {
+                    scale2 = bp[3 * COUT];
+                    shift2 = bp[4 * COUT];
+                    alpha2 = bp[5 * COUT];
+                }
+            }
+            float o1[P], o2[P];
+            const float pin = prelu_pin(alpha), pin2 = prelu_pin(alpha2);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                float v = src[p][r];
+                if (RES)
+                    v += resv[r % RR][p];
+                if (BNACT) {
+                    v = v * scale + shift;
+                    v = prelu_med3(v, alpha, pin);
+                }
+                o1[p] = v;
+                if (!VEC && STORE1)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, live ? vo[p] : OOB, so, SAUX);
+                if (DUAL) {
+                    float v2 = v * scale2 + shift2;
+                    v2 = prelu_med3(v2, alpha2, pin2);
+                    o2[p] = v2;
+                    if (!VEC)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2), rout2,
+                                                              live ? vo2[p] : OOB, so2, SAUX2);
+                }
+            }
+            if (RES && RR < M::NACC) {   // the slot just consumed is refilled at once (uniform control flow)
+                if (r + RR < M::NACC)
+                    load_res(di, r + RR);
+                else if (di + 1 < NDIL)
+                    load_res(di + 1, r + RR - M::NACC);
+            }
+            if (RES && refill_next && di + 1 < NDIL)   // F_EPI_PIPE: register r's residual of the NEXT slot, a dilation ahead of its use
+                load_res(di + 1, r);
+            if (VEC && STORE1 && !(FLAGS & F_X_NOEPIMEM))
+                buf_store_vec<P, SAUX>(rout, live ? vo[0] + so : OOB, o1);
+            if (VEC && DUAL)
+                buf_store_vec<P, SAUX2>(rout2, live ? vo2[0] + so2 : OOB, o2);
+            if (FUSE && ch0 < nout) {   // (uniform) registers whose two channels are both beyond the slot hold nothing
+                // k = lane's k-group <-> channel cb + ch0 + kq*KSTR; the table row is zero for channels beyond the slot
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    acc2[p] = M::run(a2, o1[p], acc2[p]);
+            }
+        };
+        typename M::acc_t snap[EPI_PIPED ? P : 1];   // F_EPI_PIPE: the accumulator as the previous dilation left it
+
         for (int c = 0; c < NCHUNK; ++c) {
             if (NDIL > 1 && c % CPD == 0 && prio_mode == 0) {
                 // The two waves of a SIMD run the same program; arbitration prefers the older one, which
@@ -747,6 +835,15 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                                           e == 0 && x0 == 0 && px == 0);
                         }
                     }
+                    if (EPI_PIPED && c > 0) {
+                        // the previous slot's epilogue, one accumulator register after every EPI_EVERY-th k-step (early in the
+                        // dilation: the residual reloads it issues are for this dilation's own slot)
+                        constexpr int EPI_EVERY = D / (2 * M::NACC) > 0 ? D / (2 * M::NACC) : 1;
+                        static_for<M::NACC>([&](auto r_) {   // (u is a constant once the step loops are unrolled: one call survives)
+                            if (u == decltype(r_)::value * EPI_EVERY + EPI_EVERY - 1)
+                                epi_reg(c - 1, r_, snap, true);
+                        });
+                    }
                     if (!S2P)
                         fetch_b(rs, sb, nx, g, tx, fl);
                     else if (tx == 2)
@@ -775,8 +872,12 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             // last chunk of a dilation: write this branch's concat slot (the accumulator keeps
             // running for the fusion adds)
             const int di = c / CPD;
-            const int nout = di == 0 ? NOUT1 : NOUT;
-            const int cb = di == 0 ? 0 : NOUT1 + (di - 1) * NOUT;
+            if (EPI_PIPED && di + 1 < NDIL) {   // ... between the k-steps of the next dilation, from a snapshot
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    snap[EPI_PIPED ? p : 0] = acc[p];
+                continue;
+            }
             if (XMERGE) {
                 // per-wave LDS tile [MT rows][P*MT columns]; column i is input x' = x0 - 1 + i
                 // row pitch P*MT + 4 floats: the four k-groups of a store write rows 4 apart, which a pitch of 128
@@ -814,69 +915,12 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             }
             // Branch-free epilogue: addresses are (uniform per accumulator register, in an SGPR) + (one
             // per-lane offset), so the whole slot is straight-line VALU + buffer stores.
-#pragma unroll
-            for (int r = 0; r < M::NACC; ++r) {
+            static_for<M::NACC>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
                 if ((FLAGS & F_X_STAMP2) && lane == 0 && task == t0 && r < 4)
                     a.stamp[wg * 64 + 34 + di * 4 + r] = __builtin_amdgcn_s_memrealtime();
-                const int ch0 = M::row(r, 0);   // channel held by k-group 0; group kq holds ch0 + kq*KSTR
-                const bool live = ch0 + kq * KSTR < nout;
-                // (read at the top of the register's step, not inside the uniform branch around its MFMAs: the LDS
-                // latency then runs under the BN / PReLU arithmetic instead of in front of the matrix instructions)
-                const float a2 = FUSE ? tab[(di * M::NACC + r) * 64 + lane] : 0.0f;
-                const int so = (cb + ch0) * a.out_sc * 4 + sout;
-                const int so2 = DUAL ? (a.out2_coff + cb + ch0) * a.out2_sc * 4 + sout2 : 0;
-                float scale = 1.0f, shift = 0.0f, alpha = 1.0f, scale2 = 1.0f, shift2 = 0.0f, alpha2 = 1.0f;
-                if (BNACT) {
-                    const float *bp = bnp + (live ? cb + ch0 + kq * KSTR : 0);
-                    scale = bp[0];
-                    shift = bp[COUT];
-                    alpha = bp[2 * COUT];
-                    if (DUAL) {
-                        scale2 = bp[3 * COUT];
-                        shift2 = bp[4 * COUT];
-                        alpha2 = bp[5 * COUT];
-                    }
-                }
-                float o1[P], o2[P];
-                const float pin = prelu_pin(alpha), pin2 = prelu_pin(alpha2);
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    float v = acc[p][r];
-                    if (RES)
-                        v += resv[r % RR][p];
-                    if (BNACT) {
-                        v = v * scale + shift;
-                        v = prelu_med3(v, alpha, pin);
-                    }
-                    o1[p] = v;
-                    if (!VEC && STORE1)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, live ? vo[p] : OOB, so, SAUX);
-                    if (DUAL) {
-                        float v2 = v * scale2 + shift2;
-                        v2 = prelu_med3(v2, alpha2, pin2);
-                        o2[p] = v2;
-                        if (!VEC)
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2), rout2,
-                                                                  live ? vo2[p] : OOB, so2, SAUX2);
-                    }
-                }
-                if (RES && RR < M::NACC) {   // the slot just consumed is refilled at once (uniform control flow)
-                    if (r + RR < M::NACC)
-                        load_res(di, r + RR);
-                    else if (di + 1 < NDIL)
-                        load_res(di + 1, r + RR - M::NACC);
-                }
-                if (VEC && STORE1 && !(FLAGS & F_X_NOEPIMEM))
-                    buf_store_vec<P, SAUX>(rout, live ? vo[0] + so : OOB, o1);
-                if (VEC && DUAL)
-                    buf_store_vec<P, SAUX2>(rout2, live ? vo2[0] + so2 : OOB, o2);
-                if (FUSE && ch0 < nout) {   // (uniform) registers whose two channels are both beyond the slot hold nothing
-                    // k = lane's k-group <-> channel cb + ch0 + kq*KSTR; the table row is zero for channels beyond the slot
-#pragma unroll
-                    for (int p = 0; p < P; ++p)
-                        acc2[p] = M::run(a2, o1[p], acc2[p]);
-                }
-            }
+                epi_reg(di, r_, acc, false);
+            });
             if (FUSE && di + 1 == NDIL) {
                 // the block's output is complete for this strip: its 1x1 reduce leaves for the next block's reduced map
 #pragma unroll

@@ -531,7 +531,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             {
                 if (small2)
                     return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2, CFG_L2_BR_P2S>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
-                return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
+                return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2 | EPIPE_L2_DOWN, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
             }
             return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
         }
@@ -563,12 +563,12 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             if (last) {
                 if (small2)
                     return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2, CFG_L2_BR_P2S>(with_dual(ca, 0), m->num_cus, s);
-                return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2, CFG_L2_BR_P4>(with_dual(ca, 0), m->num_cus, s);
+                return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2 | EPIPE_L2_ESP, CFG_L2_BR_P4>(with_dual(ca, 0), m->num_cus, s);
             }
             if (fuse_next) {
                 if (small2)
                     return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | FUSE_L2, CFG_L2_BR_P2S>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
-                return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | FUSE_L2, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
+                return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | FUSE_L2 | EPIPE_L2_ESP, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
             }
             return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
         });

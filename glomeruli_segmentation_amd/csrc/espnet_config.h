@@ -126,6 +126,13 @@ constexpr int SKIP_L3 = CFG_SKIP_PAD ? F_SKIP_PAD : 0;
 #endif
 
 
+// F_EPI_PIPE (round 5): the level-2 branch kernels' epilogue of concat slot d between the k-steps of dilation d + 1 (conv_mfma.h).
+// bit 0: the ESP blocks, bit 1: the down-sampler.  Measured in profiles/r05_ab_l2_epilogue.txt.
+#ifndef CFG_L2_EPI_PIPE
+#define CFG_L2_EPI_PIPE 0
+#endif
+constexpr int EPIPE_L2_ESP = (CFG_L2_EPI_PIPE & 1) ? F_EPI_PIPE : 0, EPIPE_L2_DOWN = (CFG_L2_EPI_PIPE & 2) ? F_EPI_PIPE : 0;
+
 // cache-policy flags per launch class (F_RES_NT / F_ST_NT / F_ST2_NT, conv_mfma.h)
 #ifndef POL_L2_DOWN
 #define POL_L2_DOWN (F_ST_NT | F_ST2_NT)
