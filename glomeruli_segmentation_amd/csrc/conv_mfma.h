@@ -768,6 +768,14 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             }
         };
         typename M::acc_t snap[EPI_PIPED ? P : 1];   // F_EPI_PIPE: the accumulator as the previous dilation left it
+#if defined(GS_DIAG) && defined(CFG_X_S2_EXTRA)
+        typename M::acc_t xacc[BNL ? P : 1];
+        if (BNL) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                xacc[p] = (typename M::acc_t)(0.0f);
+        }
+#endif
 
         for (int c = 0; c < NCHUNK; ++c) {
             if (NDIL > 1 && c % CPD == 0 && prio_mode == 0) {
@@ -823,6 +831,20 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                             asm volatile("" ::"v"(bv), "v"(aq[u]));
                         }
                     } else
+#endif
+#if defined(GS_DIAG) && defined(CFG_X_S2_EXTRA)
+                    // cost experiment for "level3_C as 20 extra rows of the stride-2 reduce" (profiles/r05_ab_level3c_fusion.txt; results
+                    // unchanged, time only): the four taps (ty, tx) in {1,2} x {1,2} -- the four level-2 pixels under a level-3 pixel --
+                    // each issue a second matrix instruction into a second accumulator set, as a second 32-row block would
+                    if (BNL) {
+                        int ty0x, sidxx;
+                        decode_rg(c, g, ty0x, sidxx);
+                        if (ty0x >= 1 && tx >= 1) {
+#pragma unroll
+                            for (int p = 0; p < P; ++p)
+                                xacc[p] = M::run(aq[u], bt[BNL ? g & 1 : 0][p][S2P ? tx : 0], xacc[p]);
+                        }
+                    }
 #endif
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
@@ -921,6 +943,18 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                     a.stamp[wg * 64 + 34 + di * 4 + r] = __builtin_amdgcn_s_memrealtime();
                 epi_reg(di, r_, acc, false);
             });
+#if defined(GS_DIAG) && defined(CFG_X_S2_EXTRA)
+            if (BNL) {   // keep the second set live; it would be stored as 20 more planes (5 classes x 4 level-2 pixels)
+                float keep = 0.0f;
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int r = 0; r < M::NACC; ++r)
+                        keep += xacc[p][r];
+                if (keep == 123.456f)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, keep), rout, vout, sout, 0);
+            }
+#endif
             if (FUSE && di + 1 == NDIL) {
                 // the block's output is complete for this strip: its 1x1 reduce leaves for the next block's reduced map
 #pragma unroll

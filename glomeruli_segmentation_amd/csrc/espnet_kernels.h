@@ -506,6 +506,16 @@ __global__ void __launch_bounds__(256) dec2_kernel(const Dec2Args a)
     for (int k = 0; k < CLS; ++k)
         s[k] = 0.0f;
     const int cb = 32 * w;
+#if defined(GS_DIAG) && defined(DEC2_X_NOCAT)
+    // gain ceiling for "level3_C computed elsewhere" (profiles/r05_ab_level3c_fusion.txt; results wrong by construction): dec2
+    // without its read of the 131 planes of output1_cat -- five planes of a precomputed level3_C output stand in
+    if (w == 0) {
+#pragma unroll
+        for (int k = 0; k < CLS; ++k)
+            s[k] = ld_stream<NT_DEC2_LD>(at(a.a1, n, k, y, x));
+    }
+    if (false)
+#endif
     if (cb >= a.raw_c0 && cb < a.raw_c0 + a.raw_cn) {   // (uniform) lazy b2: these planes are raw; BN + PReLU of the cat's BR here
 #pragma unroll 16
         for (int c = cb; c < cb + 32; ++c) {
@@ -525,6 +535,9 @@ __global__ void __launch_bounds__(256) dec2_kernel(const Dec2Args a)
                 s[k] = fmaf(pc[k], v, s[k]);
         }
     }
+#if defined(GS_DIAG) && defined(DEC2_X_NOCAT)
+    if (false)
+#endif
     if (w == 3) {
 #pragma unroll
         for (int c = 128; c < 131; ++c) {
