@@ -1562,3 +1562,29 @@ def test_crop_pipeline_overlays_and_counts_equal_the_host_arithmetic(torch_mod, 
         for k in range(2):
             colour[m == k] = pal[k][::-1]
         assert np.array_equal(ov, imageops.add_weighted(c, 0.25, colour, 0.75))
+
+
+@pytest.mark.parametrize("h,w", [(16, 2048), (24, 1208), (16, 776), (8, 2056), (40, 520), (16, 136), (32, 392)])
+def test_decoder_tail_strip_teams_at_other_widths(torch_mod, engine1, h, w):
+    """the decoder tail's aligned strips with boundary exchange at row widths other than the headline's 512 half-resolution pixels:
+    8 strips (a whole workgroup as one team), 5 (team of eight, three waves idle), 4 with a partial last strip, 3 (team of four), 2, 1 --
+    and 1 028 pixels, one more than a team can span, where the overlapping strips take over: logits against the oracle, the mask-only
+    kernel = the argmax of the logits kernel, counts = bincount, and a batch of three gives every image its single-image answer"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, noise_tile
+    from oracle import espnet_oracle as orc
+    mean, std = FOLD_MEAN_STD[1]
+    sd = load_weights(1)
+    tiles = np.stack([noise_tile(31 * h + w + k, h, w) for k in range(3)])
+    t = torch.from_numpy(tiles).cuda()
+    mask, hist, logits = engine1.segment(t, mean, std, want_logits=True)
+    lg_ref, mask_ref, _ = orc.segment_tile(tiles[1], sd, mean, std)
+    lg = logits.cpu().numpy()
+    assert np.abs(lg[1] - lg_ref).max() <= 5e-4 * max(1.0, np.abs(lg_ref).max())
+    m2, h2, _ = engine1.segment(t, mean, std)                       # the mask-only instantiation
+    assert torch.equal(m2, mask) and torch.equal(h2, hist)
+    assert torch.equal(mask, logits.max(1)[1].byte())
+    for k in range(3):
+        assert np.array_equal(hist[k].cpu().numpy(), np.bincount(mask[k].cpu().numpy().ravel(), minlength=5))
+        mk, hk, lk = engine1.segment(t[k:k + 1], mean, std, want_logits=True)
+        assert torch.equal(mk[0], mask[k]) and torch.equal(lk[0], logits[k])
