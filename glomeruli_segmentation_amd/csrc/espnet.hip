@@ -1047,8 +1047,8 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
                 for (int ch = 0; ch < 2 * cp; ++ch) {
                     const int sc = cat2(ch);
                     if (sc < 0) continue;
-                    for (int tap = 0; tap < 9; ++tap)
-                        v[((size_t)k * 2 * cp + ch) * 9 + tap] = w[((size_t)k * 2 * c + sc) * 9 + tap];
+                    for (int tap = 0; tap < 9; ++tap)   // (five classes: the reference's own order; else [plane][tap][class], see Dec3Args)
+                        v[cp == 5 ? ((size_t)k * 2 * cp + ch) * 9 + tap : ((size_t)ch * 9 + tap) * cp + k] = w[((size_t)k * 2 * c + sc) * 9 + tap];
                 }
             m.wcc = bb.push(v.data(), v.size());
         }

@@ -576,7 +576,8 @@ __global__ void __launch_bounds__(256) dec2_kernel(const Dec2Args a)
 // 1/4-scale pixel.  reference: Model.py:373 (335,337)
 struct Dec3Args {
     ActV t;              // 2*CLS channels
-    const float *wc;     // combine_l2_l3.1.conv.weight [CLS][2*CLS][3][3]
+    const float *wc;     // combine_l2_l3.1.conv.weight [CLS][2*CLS][3][3]; for CLS != 5 repacked [2*CLS][3][3][CLS]: the CLS weights of a
+                         // (plane, tap) are one run of scalar loads instead of CLS loads 18*CLS floats apart
     const float *bnc;    // combine_l2_l3.1 bn+act folded [3][CLS]
     const float *wup;    // up_l2.0.weight [CLS][CLS][2][2]
     const float *bnu;    // up_l2.1 folded [3][CLS]
@@ -610,7 +611,7 @@ __global__ void __launch_bounds__(256) dec3_kernel(const Dec3Args a)
                 const float v = ldz(a.t, n, c, y - 1 + ky, x - 1 + kx);
 #pragma unroll
                 for (int k = 0; k < CLS; ++k)
-                    s[k] = fmaf(a.wc[((k * 2 * CLS + c) * 3 + ky) * 3 + kx], v, s[k]);
+                    s[k] = fmaf(CLS == 5 ? a.wc[((k * 2 * CLS + c) * 3 + ky) * 3 + kx] : a.wc[((c * 3 + ky) * 3 + kx) * CLS + k], v, s[k]);
             }
     }
 #pragma unroll
