@@ -51,6 +51,94 @@ static void run(const char *name, const std::vector<uint32_t> &mask)
     hipStreamDestroy(s);
 }
 
+__global__ void spin(long long cycles, unsigned *sink)
+{
+    long long t0 = clock64();
+    while (clock64() - t0 < cycles) {}
+    if (sink && threadIdx.x == 1000) sink[0] = 1;
+}
+
+// do kernels on two streams with DISJOINT CU masks run at the same time?  (each: one 512-thread workgroup per permitted CU, ~1 ms)
+static void concurrency(int words)
+{
+    std::vector<uint32_t> low(words, 0), high(words, 0);
+    for (int i = 0; i < words / 2; ++i) low[i] = 0xffffffffu;
+    for (int i = words / 2; i < words; ++i) high[i] = 0xffffffffu;
+    hipStream_t a, b, pa, pb;
+    hipExtStreamCreateWithCUMask(&a, (uint32_t)words, low.data());
+    hipExtStreamCreateWithCUMask(&b, (uint32_t)words, high.data());
+    hipStreamCreateWithFlags(&pa, hipStreamNonBlocking);
+    hipStreamCreateWithFlags(&pb, hipStreamNonBlocking);
+    auto timeit = [&](const char *name, hipStream_t s0, hipStream_t s1, int blocks, size_t lds) {
+        hipDeviceSynchronize();
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        for (int rep = 0; rep < 2; ++rep) {
+            hipDeviceSynchronize();
+            hipEventRecord(e0, s0);
+            hipLaunchKernelGGL(spin, dim3(blocks), dim3(512), lds, s0, 2400000ll, nullptr);
+            if (s1) hipLaunchKernelGGL(spin, dim3(blocks), dim3(512), lds, s1, 2400000ll, nullptr);
+            hipStreamSynchronize(s0);
+            if (s1) hipStreamSynchronize(s1);
+            hipEventRecord(e1, s0);
+            hipEventSynchronize(e1);
+        }
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        std::printf("%-58s %.2f ms\n", name, ms);
+    };
+    timeit("one masked stream, 128 blocks", a, nullptr, 128, 0);
+    timeit("two masked streams (disjoint halves), 128 blocks each", a, b, 128, 0);
+    timeit("two plain streams, 128 blocks each", pa, pb, 128, 0);
+    timeit("two masked streams, 128 blocks each, 128 KB LDS per block", a, b, 128, 128 * 1024);
+    timeit("two plain streams, 256 blocks each, 128 KB LDS per block", pa, pb, 256, 128 * 1024);
+}
+
+// CHAINS of kernels (as a forward is) on two CU-masked streams: does the second stream's chain run beside the first's, or after it?
+static void chains(int words)
+{
+    std::vector<uint32_t> low(words, 0), high(words, 0);
+    for (int i = 0; i < words / 2; ++i) low[i] = 0xffffffffu;
+    for (int i = words / 2; i < words; ++i) high[i] = 0xffffffffu;
+    const int NS = 8;
+    hipStream_t sa[NS], sb[NS], plain[2];
+    for (int k = 0; k < NS; ++k) {
+        (void)hipExtStreamCreateWithCUMask(&sa[k], (uint32_t)words, low.data());
+        (void)hipExtStreamCreateWithCUMask(&sb[k], (uint32_t)words, high.data());
+    }
+    (void)hipStreamCreateWithFlags(&plain[0], hipStreamNonBlocking);
+    (void)hipStreamCreateWithFlags(&plain[1], hipStreamNonBlocking);
+    auto run2 = [&](const char *name, hipStream_t s0, hipStream_t s1, int blocks) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipDeviceSynchronize();
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, s0);
+            for (int k = 0; k < 10; ++k) {
+                hipLaunchKernelGGL(spin, dim3(blocks), dim3(512), 0, s0, 480000ll, nullptr);
+                hipLaunchKernelGGL(spin, dim3(blocks), dim3(512), 0, s1, 480000ll, nullptr);
+            }
+            (void)hipStreamSynchronize(s1);
+            (void)hipEventRecord(e1, s0);
+            (void)hipEventSynchronize(e1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            best = ms < best ? ms : best;
+        }
+        std::printf("%-64s %.2f ms  (10 x 0.2 ms per stream: 2.0 side by side, 4.0 one after the other)\n", name, best);
+    };
+    run2("chains on two plain streams, 128 blocks", plain[0], plain[1], 128);
+    for (int k = 0; k < NS; ++k) {
+        char name[96];
+        std::snprintf(name, sizeof name, "chains on masked streams low[0] + high[%d], 128 blocks", k);
+        run2(name, sa[0], sb[k], 128);
+    }
+    run2("chains on masked streams low[3] + high[5], 128 blocks", sa[3], sb[5], 128);
+}
+
 int main()
 {
     hipDeviceProp_t p;
@@ -75,5 +163,8 @@ int main()
     run("bits 0-7 only", one);
     one[0] = 0xff00;
     run("bits 8-15 only", one);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(spin), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    concurrency(words);
+    chains(words);
     return 0;
 }
