@@ -69,8 +69,6 @@ PROTOTYPES = {
     "gs_espnet_forward": (_I, [_P, _P, _I, _I, _I, _I, _FP, _FP, _P, _P, _P, _P]),
     "gs_espnet_set_lanes": (_I, [_P, _I]),
     "gs_espnet_lanes": (_I, [_P]),
-    "gs_espnet_partition_lanes": (_I, [_P, _I]),
-    "gs_espnet_lane_stream": (_P, [_P, _I]),
     "gs_espnet_forward_lane": (_I, [_P, _I, _P, _I, _I, _I, _I, _FP, _FP, _P, _P, _P, _P]),
     "gs_espnet_segment_host": (_I, [_P, _P, _I, _I, _I, _FP, _FP, _I, _P, _P]),
     "gs_espnet_segment_crops": (_I, [_P, _I, _P, ctypes.POINTER(CropDesc), _I, _FP, _FP, _I, _I, _P, _P, _P,

@@ -858,9 +858,6 @@ struct gs_espnet {
     Model m;
     std::vector<std::unique_ptr<Model>> lanes;   // lane k >= 1 is lanes[k - 1]
     hipStream_t pipe_compute2 = nullptr;         // gs_espnet_segment_host: the second of its two streams (odd batches)
-    int parts = 1;                               // gs_espnet_partition_lanes: lanes 0 .. parts-1 each own 1/parts of every XCD's CUs
-    hipStream_t part_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // ... and a CU-masked stream
-    int dev_cus = 0;
     gs::CropPipe *crop_pipe = nullptr;           // gs_espnet_segment_crops*: staging state (csrc/crops.hip)
     Model &lane(int k) { return k == 0 ? m : *lanes[k - 1]; }
 };
@@ -943,7 +940,6 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
         return GS_ERR_NODEVICE;
     }
     m.num_cus = prop.multiProcessorCount;
-    h->dev_cus = m.num_cus;
 #ifdef GS_DIAG
     if (const char *v = std::getenv("GS_VARIANT"))
         m.variant = std::atoi(v);
@@ -1159,8 +1155,6 @@ void gs_espnet_destroy(gs_espnet *h)
     if (h->m.pipe_compute) hipStreamDestroy(h->m.pipe_compute);
     if (h->m.pipe_h2d) hipStreamDestroy(h->m.pipe_h2d);
     if (h->pipe_compute2) hipStreamDestroy(h->pipe_compute2);
-    for (auto &ps : h->part_stream)
-        if (ps) hipStreamDestroy(ps);
     for (auto &l : h->lanes) {
         for (auto &ev : l->events) {
             hipEventDestroy(ev.a);
@@ -1198,7 +1192,6 @@ gs_status gs_espnet_set_lanes(gs_espnet *h, int n_lanes)
 {
     GS_REQUIRE(h, "null handle");
     GS_REQUIRE(n_lanes >= 1 && n_lanes <= 4, "gs_espnet_set_lanes: 1 to 4 lanes (got %d)", n_lanes);
-    GS_REQUIRE(h->parts == 1, "gs_espnet_set_lanes: the lanes are partitioned (gs_espnet_partition_lanes(h, 1) first)");
     GS_HIP(hipDeviceSynchronize());
     while ((int)h->lanes.size() > n_lanes - 1) {
         if (h->lanes.back()->ws) hipFree(h->lanes.back()->ws);
@@ -1226,49 +1219,6 @@ gs_status gs_espnet_set_lanes(gs_espnet *h, int n_lanes)
 
 int gs_espnet_lanes(gs_espnet *h) { return h ? 1 + (int)h->lanes.size() : 0; }
 
-gs_status gs_espnet_partition_lanes(gs_espnet *h, int parts)
-{
-    GS_REQUIRE(h, "null handle");
-    GS_REQUIRE(parts == 1 || parts == 2 || parts == 4, "gs_espnet_partition_lanes: 1 (off), 2 or 4 parts (got %d)", parts);
-    GS_REQUIRE(parts <= 1 + (int)h->lanes.size(), "gs_espnet_partition_lanes: %d parts need %d lanes (gs_espnet_set_lanes)", parts, parts);
-    GS_REQUIRE(parts == 1 || (h->dev_cus % (8 * parts) == 0), "gs_espnet_partition_lanes: %d compute units do not split into %d parts of whole CUs per XCD", h->dev_cus, parts);
-    GS_HIP(hipDeviceSynchronize());
-    for (auto &ps : h->part_stream) {
-        if (ps) hipStreamDestroy(ps);
-        ps = nullptr;
-    }
-    for (int k = 0; k <= (int)h->lanes.size(); ++k)
-        h->lane(k).num_cus = h->dev_cus;
-    h->parts = 1;
-    if (parts == 1)
-        return GS_OK;
-    // CU-mask bit i names compute unit i / 8 of XCD i % 8 (tools/micro/cumask_probe.hip), so a contiguous range of dev_cus / parts
-    // bits is the same 1 / parts of EVERY XCD: a part keeps all eight L2s and the blockIdx % 8 grouping of the kernels
-    const int words = (h->dev_cus + 31) / 32, per = h->dev_cus / parts;
-    for (int k = 0; k < parts; ++k) {
-        std::vector<uint32_t> mask(words, 0u);
-        for (int b = k * per; b < (k + 1) * per; ++b)
-            mask[b / 32] |= 1u << (b % 32);
-        if (hipExtStreamCreateWithCUMask(&h->part_stream[k], (uint32_t)words, mask.data()) != hipSuccess) {
-            (void)hipGetLastError();
-            for (auto &ps : h->part_stream) {
-                if (ps) hipStreamDestroy(ps);
-                ps = nullptr;
-            }
-            set_error("gs_espnet_partition_lanes: hipExtStreamCreateWithCUMask failed");
-            return GS_ERR_HIP;
-        }
-        h->lane(k).num_cus = per;
-    }
-    h->parts = parts;
-    return GS_OK;
-}
-
-void *gs_espnet_lane_stream(gs_espnet *h, int lane)
-{
-    return (h && lane >= 0 && lane < h->parts && h->parts > 1) ? h->part_stream[lane] : nullptr;
-}
-
 gs_status gs_espnet_forward(gs_espnet *h, const void *in, int in_format, int n, int height, int width,
                             const float mean[3], const float std[3], float *logits, uint8_t *mask,
                             unsigned long long *hist, void *hip_stream)
@@ -1287,8 +1237,6 @@ gs_status gs_espnet_forward_lane(gs_espnet *h, int lane, const void *in, int in_
     GS_REQUIRE(in_format == GS_IN_U8_BGR_NHWC || in_format == GS_IN_F32_NCHW, "unknown input format %d", in_format);
     GS_REQUIRE(in_format != GS_IN_U8_BGR_NHWC || (mean && std), "uint8 input needs mean and std");
     Model &m = h->lane(lane);
-    GS_REQUIRE(h->parts == 1 || lane >= h->parts || hip_stream == h->part_stream[lane],
-               "lane %d owns a partition of the compute units (gs_espnet_partition_lanes): submit its work on gs_espnet_lane_stream(h, %d)", lane, lane);
     if (m.encoder_only) {
         GS_REQUIRE(logits && !mask && !hist, "ESPNet-C handle: only the 1/8-scale logits output exists");
     } else {

@@ -88,17 +88,6 @@ class EspnetEngine:
             _lib.check(self.lib.gs_espnet_set_lanes(self.handle, int(n)))
         self.lanes = int(n)
 
-    def partition_lanes(self, parts):
-        """lanes 0 .. parts-1 each on 1 / parts of every XCD's compute units (gs_espnet_partition_lanes); parts = 1 switches it off.
-        The lanes' streams become the library's CU-masked ones."""
-        self.quiesce()
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.gs_espnet_partition_lanes(self.handle, int(parts)))
-        self.parts = int(parts)
-        self._lane_streams = {}
-        for k in range(self.parts if self.parts > 1 else 0):
-            self._lane_streams[k] = torch.cuda.ExternalStream(self.lib.gs_espnet_lane_stream(self.handle, k), device=self.device)
-
     def lane_stream(self, lane):
         """the torch stream lane `lane` runs on (created on first use)"""
         if not 0 <= lane < self.lanes:

@@ -101,12 +101,6 @@ gs_status gs_espnet_forward(gs_espnet *h, const void *in, int in_format, int n, 
  * the handle has them. */
 gs_status gs_espnet_set_lanes(gs_espnet *h, int n_lanes);
 int gs_espnet_lanes(gs_espnet *h);
-/* PARTITIONED LANES (round 5, experimental until measured on the driver's box): lanes 0 .. parts-1 each get 1 / parts of the compute
- * units of EVERY XCD (a CU-masked HIP stream, hipExtStreamCreateWithCUMask) and size their launches for that share, so that `parts`
- * batches run side by side instead of taking turns on the whole chip.  parts = 1 switches it off.  While it is on, work for lane k <
- * parts must be submitted on gs_espnet_lane_stream(h, k) (checked); the host pipelines do so themselves. */
-gs_status gs_espnet_partition_lanes(gs_espnet *h, int parts);
-void *gs_espnet_lane_stream(gs_espnet *h, int lane); /* the lane's CU-masked stream, NULL when the lanes are not partitioned */
 gs_status gs_espnet_forward_lane(gs_espnet *h, int lane, const void *in, int in_format, int n, int height, int width,
                                  const float mean[3], const float std[3], float *logits, uint8_t *mask,
                                  unsigned long long *hist, void *hip_stream);
