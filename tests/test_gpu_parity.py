@@ -1588,3 +1588,42 @@ def test_decoder_tail_strip_teams_at_other_widths(torch_mod, engine1, h, w):
         assert np.array_equal(hist[k].cpu().numpy(), np.bincount(mask[k].cpu().numpy().ravel(), minlength=5))
         mk, hk, lk = engine1.segment(t[k:k + 1], mean, std, want_logits=True)
         assert torch.equal(mk[0], mask[k]) and torch.equal(lk[0], logits[k])
+
+
+def test_crop_overlay_destination_layouts_through_the_c_abi(torch_mod, engine1):
+    """gs_espnet_segment_crops_host's overlay output for the three kinds of caller buffers: one page-locked block laid out like the
+    packed input (what engine.segment_crops allocates: a batch per DMA), page-locked buffers that are NOT one block (a DMA per crop),
+    and pageable numpy arrays (staged through the pipeline's pinned slot): the same bytes; a palette of 65 colours is refused"""
+    import ctypes
+    torch = torch_mod
+    from glomeruli_segmentation_amd import _lib, imageops
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD
+    lib = _lib.load()
+    mean, std = FOLD_MEAN_STD[1]
+    crops = _crops([(50, 70), (33, 35), (64, 128), (90, 41), (12, 300)], 1500)
+    ref = engine1.segment_crops(crops, mean, std, 64, 128, batch=2, overlay=(imageops.PALETTE, 0.4, 0.6))
+    n = len(crops)
+    ptrs = (ctypes.c_void_p * n)(*[c.ctypes.data for c in crops])
+    hs = (ctypes.c_int * n)(*[c.shape[0] for c in crops])
+    ws = (ctypes.c_int * n)(*[c.shape[1] for c in crops])
+    handles = (ctypes.c_void_p * 1)(engine1.handle)
+    pal = np.ascontiguousarray(imageops.PALETTE, dtype=np.uint8)
+
+    def run(outs, n_colours=len(pal)):
+        ov = _lib.CropOverlay()
+        ov.palette_rgb = pal.ctypes.data
+        ov.n_colours = n_colours
+        ov.wa, ov.wb = 0.4, 0.6
+        arr = (ctypes.c_void_p * n)(*outs)
+        ov.out_bgr = ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
+        engine1.quiesce()
+        return lib.gs_espnet_segment_crops_host(handles, 1, ptrs, hs, ws, n, _lib.fptr3(mean), _lib.fptr3(std), 64, 128, 2, None, None, None,
+                                                None, None, None, ctypes.byref(ov))
+    pageable = [np.zeros(c.shape, np.uint8) for c in crops]
+    assert run([a.ctypes.data for a in pageable]) == 0
+    separate = [torch.zeros(c.shape, dtype=torch.uint8).pin_memory() for c in crops]
+    assert run([t.data_ptr() for t in separate]) == 0
+    for k in range(n):
+        assert np.array_equal(pageable[k], ref["overlays"][k]), k
+        assert np.array_equal(separate[k].numpy(), ref["overlays"][k]), k
+    assert run([a.ctypes.data for a in pageable], n_colours=65) != 0 and b"65" in lib.gs_last_error()
