@@ -1627,3 +1627,41 @@ def test_crop_overlay_destination_layouts_through_the_c_abi(torch_mod, engine1):
         assert np.array_equal(pageable[k], ref["overlays"][k]), k
         assert np.array_equal(separate[k].numpy(), ref["overlays"][k]), k
     assert run([a.ctypes.data for a in pageable], n_colours=65) != 0 and b"65" in lib.gs_last_error()
+
+
+def test_driver_with_seven_classes_and_gpu_overlay_files(torch_mod, tmp_path):
+    """the segment command line with `--classes 7` (a random-weight ESPNet(7, 2, 3) saved as .npz): it runs, the class maps hold classes
+    beyond 4, `summary_pixel.csv` keeps the reference's five named columns (= the counts of classes 0..4 of the written class map), and the
+    overlay JPEG -- blended on the GPU since round 5 -- is byte for byte the file the host arithmetic (imageops.add_weighted over
+    imageops.colourise, VisualizeResults_iou.py:139-146) encodes to"""
+    import filecmp
+    from PIL import Image
+    from glomeruli_segmentation_amd import imageops, segment
+    from glomeruli_segmentation_amd.synth import noise_tile
+    sd = random_state_dict(2, 3, classes=7, seed=1007)
+    wpath = tmp_path / "seven.npz"
+    np.savez(wpath, **sd)
+    d = tmp_path / "org_image" / "S0"
+    d.mkdir(parents=True)
+    crops = {}
+    for k, (h, w) in enumerate([(64, 128), (90, 70), (33, 200)]):
+        crops[k] = noise_tile(800 + k, h, w)
+        Image.fromarray(np.ascontiguousarray(crops[k][:, :, ::-1])).save(d / ("xmin%d_ymin0_xmax9_ymax9.PNG" % k))
+    out = tmp_path / "results"
+    rc = segment.main(["--rgb_data_dir", str(tmp_path / "org_image"), "--savedir", str(out), "--weights", str(wpath), "--gpu_id", "0",
+                       "--classes", "7", "--p", "2", "--q", "3", "--inWidth", "128", "--inHeight", "64", "--mean", "120", "130", "110",
+                       "--std", "60", "55", "70", "--colored", "--overlay", "--batch", "2"])
+    assert rc == 0
+    rows = open(out / "summary_pixel.csv").read().strip().splitlines()
+    assert len(rows) == 4 and all(len(r.split(",")) == 7 for r in rows)
+    seen = set()
+    for k in range(3):
+        stem = "xmin%d_ymin0_xmax9_ymax9" % k
+        cm = np.asarray(Image.open(out / "S0" / (stem + "_classmap.png")))
+        assert cm.shape == crops[k].shape[:2] and cm.max() <= 6
+        seen |= set(np.unique(cm).tolist())
+        assert [int(v) for v in rows[1 + k].split(",")[2:]] == [int(np.count_nonzero(cm == c)) for c in range(5)]
+        ref = tmp_path / ("ref_overlay_%d.jpg" % k)
+        imageops.imwrite_bgr(str(ref), imageops.add_weighted(crops[k], 0.4, imageops.colourise(cm), 0.6))
+        assert filecmp.cmp(ref, out / "S0" / (stem + "_overlay.jpg"), shallow=False), k
+    assert max(seen) >= 5
