@@ -1665,3 +1665,31 @@ def test_driver_with_seven_classes_and_gpu_overlay_files(torch_mod, tmp_path):
         imageops.imwrite_bgr(str(ref), imageops.add_weighted(crops[k], 0.4, imageops.colourise(cm), 0.6))
         assert filecmp.cmp(ref, out / "S0" / (stem + "_overlay.jpg"), shallow=False), k
     assert max(seen) >= 5
+
+
+@pytest.mark.parametrize("classes", [4, 6, 8, 9, 10, 11, 13, 14, 15, 17, 18, 19])
+def test_every_other_class_count_against_the_oracle(torch_mod, classes):
+    """the class counts the reference goldens do not name (tests/golden/classes.npz holds 20, 16, 12, 7, 3, 2): the same padded
+    instantiations with another run-time class count, ESPNet(classes, 1, 1) with random weights against the CPU oracle on a ragged tile --
+    logits, first-max mask, counts over `classes` bins, and the 1/8-scale logits of ESPNet-C"""
+    torch = torch_mod
+    from glomeruli_segmentation_amd.engine import EspnetEngine
+    from glomeruli_segmentation_amd.synth import noise_tile
+    from oracle import espnet_oracle as orc
+    sd = random_state_dict(1, 1, classes=classes, seed=300 + classes)
+    mean, std = (120.0, 130.0, 110.0), (60.0, 55.0, 70.0)
+    tile = noise_tile(40 + classes, 40, 264)
+    lg_ref, mask_ref, hist_ref = orc.segment_tile(tile, sd, mean, std, 1, 1)
+    eng = EspnetEngine(sd, classes=classes, p=1, q=1)
+    mask, hist, logits = eng.segment(torch.from_numpy(tile[None]).cuda(), mean, std, want_logits=True)
+    assert np.abs(logits[0].cpu().numpy() - lg_ref).max() <= 5e-4 * max(1.0, float(np.abs(lg_ref).max()))
+    m = mask[0].cpu().numpy()
+    assert (m != mask_ref).mean() <= 2e-3 and np.array_equal(m, logits[0].max(0)[1].byte().cpu().numpy())
+    assert np.array_equal(hist[0].cpu().numpy(), np.bincount(m.ravel(), minlength=classes)) and hist.shape == (1, classes)
+    eng.close()
+    sde = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    enc = EspnetEngine(sde, classes=classes, p=1, q=1, encoder_only=True)
+    out = enc.forward_logits(torch.from_numpy(orc.preprocess(tile, mean, std)[None]).cuda())[0].cpu().numpy()
+    ref = orc.espnet_encoder_forward(orc.preprocess(tile, mean, std), sde, 1, 1)
+    assert out.shape == ref.shape == (classes, 5, 33) and np.abs(out - ref).max() <= 5e-4 * max(1.0, float(np.abs(ref).max()))
+    enc.close()
