@@ -716,7 +716,7 @@ overlay_kernel(const unsigned char *region, const unsigned char *cls, long long 
     for (int ch = 0; ch < 3; ++ch) {
         // palette rows are RGB, the image is BGR (classMap_numpy_color[...] = [b, g, r])
         const float col = c < ncol ? (float)pal[c * 3 + (2 - ch)] : 0.0f;
-        const float v = (float)region[idx * 3 + ch] * wa + col * wb;
+        const float v = __fadd_rn(__fmul_rn((float)region[idx * 3 + ch], wa), __fmul_rn(col, wb));   // (no fused multiply-add: numpy's roundings)
         out[idx * 3 + ch] = (unsigned char)fminf(fmaxf(rintf(v), 0.0f), 255.0f);   // saturate_cast<uchar>(cvRound)
     }
 }

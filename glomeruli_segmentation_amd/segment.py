@@ -92,18 +92,46 @@ def segment_batch(engine, images, mean, std, width, height, batch, want_net_maps
     crop-size maps) and overlays (the palette-coloured map blended over the crop, BGR | None) -- counts and overlays come out of
     the batched crop pipeline with the maps (gs_espnet_segment_crops_host: crops_back_kernel counts, crops_overlay_kernel
     blends), the host only encodes.  ESPNet-C (modelType 2) has no such pipeline: its maps come from segment_images and the
-    two by-products from the same arithmetic on the host."""
+    two by-products from _byproducts (on the GPU as well)."""
     if engine.encoder_only or not images:
         masks, net = segment_images(engine, images, mean, std, width, height, batch, want_net_maps=True)
-        counts = np.array([np.bincount(np.asarray(m).ravel(), minlength=engine.classes)[:engine.classes] for m in masks],
-                          dtype=np.int64).reshape(len(masks), engine.classes)
-        overlays = [imageops.add_weighted(im, OVERLAY_WEIGHTS[0], imageops.colourise(m), OVERLAY_WEIGHTS[1])
-                    for im, m in zip(images, masks)] if want_overlay else None
+        counts, overlays = _byproducts(engine, images, masks, want_overlay)
         return {"masks": masks, "net_maps": net if want_net_maps else None, "counts": counts, "overlays": overlays}
     r = engine.segment_crops(images, mean, std, height, width, batch, want_masks=True, want_net_maps=want_net_maps, want_hist=True,
                              overlay=(imageops.PALETTE, OVERLAY_WEIGHTS[0], OVERLAY_WEIGHTS[1]) if want_overlay else None)
     return {"masks": r["masks"], "net_maps": list(r["net_maps"]) if want_net_maps else None, "counts": r["counts"],
             "overlays": r["overlays"]}
+
+
+def _byproducts(engine, images, masks, want_overlay):
+    """counts (:151-155) and overlays (:139-146) of class maps that did not come out of the batched crop pipeline (ESPNet-C): on the
+    engine's GPU when it has one -- torch.bincount and gs_overlay_classmap, the arithmetic of crops_overlay_kernel -- else (the CPU tests'
+    stand-in engines) the same arithmetic in numpy"""
+    classes = engine.classes
+    dev = getattr(engine, "device", None)
+    if dev is None or not hasattr(engine, "lib"):
+        counts = np.array([np.bincount(np.asarray(m).ravel(), minlength=classes)[:classes] for m in masks], dtype=np.int64).reshape(len(masks), classes)
+        overlays = [imageops.add_weighted(im, OVERLAY_WEIGHTS[0], imageops.colourise(m), OVERLAY_WEIGHTS[1])
+                    for im, m in zip(images, masks)] if want_overlay else None
+        return counts, overlays
+    import ctypes
+    import torch
+    from . import _lib
+    pal = torch.from_numpy(np.ascontiguousarray(imageops.PALETTE)).to(dev)
+    counts = np.zeros((len(masks), classes), dtype=np.int64)
+    overlays = [] if want_overlay else None
+    with torch.cuda.device(dev):
+        for i, (im, m) in enumerate(zip(images, masks)):
+            mg = torch.from_numpy(np.ascontiguousarray(m)).to(dev)
+            counts[i] = torch.bincount(mg.flatten().long(), minlength=classes)[:classes].cpu().numpy()
+            if want_overlay:
+                ig = torch.from_numpy(np.ascontiguousarray(im)).to(dev)
+                out = torch.empty_like(ig)
+                _lib.check(engine.lib.gs_overlay_classmap(ig.data_ptr(), mg.data_ptr(), int(m.shape[0]), int(m.shape[1]), pal.data_ptr(),
+                                                          int(pal.shape[0]), ctypes.c_float(OVERLAY_WEIGHTS[0]), ctypes.c_float(OVERLAY_WEIGHTS[1]),
+                                                          out.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+                overlays.append(out.cpu().numpy())
+    return counts, overlays
 
 
 def segment_images(engine, images, mean, std, width, height, batch, want_net_maps=False):

@@ -443,13 +443,21 @@ def test_driver_model_type_2(torch_mod, tmp_path):
     rc = segment.main(["--rgb_data_dir", str(tmp_path / "org_image"), "--savedir", str(out), "--weights",
                        os.path.join(GOLDEN, "weights_fold1.npz"), "--gpu_id", "0", "--modelType", "2", "--inWidth", str(w),
                        "--inHeight", str(h), "--mean", "204.60071", "170.19359", "199.57469", "--std", "20.61257", "42.92207",
-                       "28.401505"])
+                       "28.401505", "--colored", "--overlay"])
     assert rc == 0
     exp = torch.nn.functional.interpolate(torch.from_numpy(z["out"])[None], scale_factor=8, mode="bilinear",
                                           align_corners=False)[0].max(0)[1].numpy()
     cm = np.asarray(Image.open(out / "PAS-002" / "xmin0_ymin0_xmax1_ymax1_classmap.png"))
     assert cm.shape == exp.shape
     assert (cm != exp).mean() <= 1e-3
+    # the by-products of this path (counts by torch.bincount, overlay by gs_overlay_classmap) are the host arithmetic's, byte for byte
+    import filecmp
+    from glomeruli_segmentation_amd import imageops
+    row = open(out / "summary_pixel.csv").read().strip().splitlines()[1]
+    assert [int(v) for v in row.split(",")[2:]] == [int(np.count_nonzero(cm == c)) for c in range(5)]
+    ref = tmp_path / "ref_overlay.jpg"
+    imageops.imwrite_bgr(str(ref), imageops.add_weighted(tile, 0.4, imageops.colourise(cm), 0.6))
+    assert filecmp.cmp(ref, out / "PAS-002" / "xmin0_ymin0_xmax1_ymax1_overlay.jpg", shallow=False)
 
 
 def test_detector_primitives_self_consistency(torch_mod):
