@@ -81,6 +81,7 @@ struct Model {
     // offsets (floats) into dblob
     float stem_params[537] = {0};   // host copy of level1 weights + folded bn1 + folded b1: they travel as kernel arguments
     long long w1, bn1, b1, b2, b3, wcls, br, wup3, w3c, cbr0, wcc, bncc, wup2, bnu2, wconv, wconv_xm, wclassifier, wtail;
+    long long wcc_mfma = -1;   // twelve classes and more: combine_l2_l3.1 as a conv_mfma image (see forward_impl)
     PackedConv l2_0;
     std::vector<PackedConv> l2, l3;
     PackedConv l3_0;
@@ -89,7 +90,7 @@ struct Model {
     void *ws = nullptr;
     size_t ws_bytes = 0;
     int ws_n = 0, ws_h = 0, ws_w = 0;
-    Act a0c, a0, inp1, inp2, r2[2], bb[3], a1, r3[2], cc[3], o2c, tt, ee, ff;
+    Act a0c, a0, inp1, inp2, r2[2], bb[3], a1, r3[2], cc[3], o2c, tt, t3, ee, ff;
     float *prob = nullptr;   // ensemble scratch
     size_t prob_bytes = 0;
     std::map<std::string, std::pair<Act, int>> stages;   // name -> (activation, channels) of the last forward
@@ -302,7 +303,10 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
     for (int i = 0; i < 3; ++i)
         m->cc[i] = make_act(128, 128, H3, W3, 0, 0, 0, 0);
     m->o2c = make_act(cls, cls, H2, W2, 0, 0, 0, 0);
-    m->tt = make_act(2 * cls, 2 * cls, H2, W2, 0, 0, 0, 0);
+    // (twelve classes and more: combine_l2_l3.1's 3x3 runs on the matrix cores and reads its input with a zero halo; t3 is its output)
+    const bool dec3_mfma = cls >= 12;
+    m->tt = dec3_mfma ? make_act(2 * cls, 2 * cls, H2, W2, 1, 1, 32, 1) : make_act(2 * cls, 2 * cls, H2, W2, 0, 0, 0, 0);
+    m->t3 = dec3_mfma ? make_act(cls, cls, H2, W2, 0, 0, 0, 0) : make_act(1, 1, 8, 8, 0, 0, 0, 0);
     m->ff = make_act(cls, cls, H1, W1, 0, 0, 0, 0);
     // Lazy b2 (p > 0): output1_0 is stored RAW, once, straight into planes 64..127 of output1_cat -- bb[0] becomes a view of
     // them -- and the consumers of output1_cat apply b2 to those planes on load (CFG_LAZY_B2 above).
@@ -310,7 +314,7 @@ static gs_status layout_workspace(Model *m, int n, int H, int W)
     if (lazy_b2)
         m->bb[0] = Act();   // no storage of its own
     Act *all[] = {&m->a0c, &m->inp1, &m->inp2, &m->r2[0], &m->r2[1], &m->bb[0], &m->bb[1], &m->bb[2], &m->a1, &m->r3[0], &m->r3[1],
-                  &m->cc[0], &m->cc[1], &m->cc[2], &m->o2c, &m->tt, &m->ff};
+                  &m->cc[0], &m->cc[1], &m->cc[2], &m->o2c, &m->tt, &m->t3, &m->ff};
     for (Act *a : all) {   // kernels address one image with 32-bit byte offsets (buffer soffset / voffset)
         if ((unsigned long long)a->sn * sizeof(float) >= (1ull << 31)) {
             set_error("tile %dx%d is too large: an activation of one image exceeds 2 GiB", H, W);
@@ -715,19 +719,42 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     if (ncls == CLS)   // (with padding planes in between the two halves are not one contiguous stage)
         set_stage("combine_t", m->tt, 2 * CLS);
     // ---- CBR(2c,c,3) + up_l2 (Model.py:373)
-    L.run(K_DEC3, px2 * (2 * ncls * 9 * ncls * 2) + px2 * (ncls * ncls * 4 * 2), [&] {
-        Dec3Args a{};
-        a.t = view(m->tt);
-        a.wc = wb + m->wcc;
-        a.bnc = wb + m->bncc;
-        a.wup = wb + m->wup2;
-        a.bnu = wb + m->bnu2;
-        a.e = view(m->ee);
-        a.N = n;
-        a.classes = ncls;
-        hipLaunchKernelGGL(dec3_kernel<CLS>, dim3(blocks_for((long long)n * H2 * W2)), dim3(256), 0, s, a);
-        return GS_OK;
-    });
+    if constexpr (CLS >= 12) {
+        // many classes: the 3x3 over 2 * CLS planes is 7 200 FMAs per pixel at twenty classes -- on the matrix cores (a plain
+        // conv_mfma launch, BN + PReLU in its epilogue), the deconvolution + BR as a second, small kernel
+        L.run(K_DEC3, px2 * (2 * ncls * 9 * ncls * 2), [&] {
+            const ConvArgs ca = conv_args(m->tt, wb + m->wcc_mfma, m->t3, nullptr, n);
+            if constexpr (CLS <= 16)
+                return launch_vec<F_BNACT, 16, 8, 2 * CLS, 9, 1, 1, CLS, CLS, 8, 3>(ca, m->num_cus, s);
+            else
+                return launch_vec<F_BNACT, 32, 8, 2 * CLS, 9, 1, 1, CLS, CLS, 4, 3>(ca, m->num_cus, s);
+        });
+        L.run(K_DEC3, px2 * (ncls * ncls * 4 * 2), [&] {
+            Dec3Args a{};
+            a.t = view(m->t3);
+            a.wup = wb + m->wup2;
+            a.bnu = wb + m->bnu2;
+            a.e = view(m->ee);
+            a.N = n;
+            a.classes = ncls;
+            hipLaunchKernelGGL(dec3b_kernel<CLS>, dim3(blocks_for((long long)n * H2 * W2)), dim3(256), 0, s, a);
+            return GS_OK;
+        });
+    } else {
+        L.run(K_DEC3, px2 * (2 * ncls * 9 * ncls * 2) + px2 * (ncls * ncls * 4 * 2), [&] {
+            Dec3Args a{};
+            a.t = view(m->tt);
+            a.wc = wb + m->wcc;
+            a.bnc = wb + m->bncc;
+            a.wup = wb + m->wup2;
+            a.bnu = wb + m->bnu2;
+            a.e = view(m->ee);
+            a.N = n;
+            a.classes = ncls;
+            hipLaunchKernelGGL(dec3_kernel<CLS>, dim3(blocks_for((long long)n * H2 * W2)), dim3(256), 0, s, a);
+            return GS_OK;
+        });
+    }
     set_stage("up_l2", m->ee, ncls);
     // ---- conv CBR(19+c,c,3) + classifier deconv + argmax + counts (Model.py:375-377, VisualizeResults_iou.py:128,151-155)
     if constexpr (CLS == 5) {
@@ -768,6 +795,8 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         L.run(K_DEC_CONV, px1 * ((19 + ncls) * 9 * ncls * 2), [&] {
             const ConvArgs ca = conv_args(m->a0c, wb + m->wconv, m->ff, nullptr, n);
             constexpr int CINP = (19 + CLS + 3) / 4 * 4;
+            // (deeper operand rings and four pixels per lane were measured on these launches: no gain -- at twenty classes the launch is
+            // at 90 % of what its padded matrix work allows, 20 of 32 rows)
             if constexpr (CLS <= 16)
                 return launch_vec<F_BNACT | POL_DEC_CONV, 16, 8, CINP, 9, 1, 1, CLS, CLS, 8, 3>(ca, m->num_cus, s);
             else
@@ -1052,10 +1081,23 @@ gs_status gs_espnet_create(const float *blob, const gs_layer_desc *table, int n_
                 }
             m.wcc = bb.push(v.data(), v.size());
         }
+        if (cp >= 12) {   // the same convolution as a conv_mfma image: [tap][2 * cp planes][cp rows], then its folded BN + PReLU
+            m.wcc_mfma = bb.reserve(conv_wfloats(2 * cp, 9, 1, cp, cp, true));
+            float *dst = bb.data.data() + m.wcc_mfma;
+            for (int tap = 0; tap < 9; ++tap)
+                for (int ch = 0; ch < 2 * cp; ++ch) {
+                    const int sc = cat2(ch);
+                    if (sc < 0) continue;
+                    for (int k = 0; k < c; ++k)
+                        dst[((size_t)tap * 2 * cp + ch) * cp + k] = w[((size_t)k * 2 * c + sc) * 9 + tap];
+                }
+        }
         if (!fold_bn(t, "combine_l2_l3.1.bn", "combine_l2_l3.1.act", c, tmp.data())) return GS_ERR_INVALID;
         {
             const std::vector<float> v = pad_bn(tmp.data(), c, 3, cp, ident);
             m.bncc = bb.push(v.data(), v.size());
+            if (m.wcc_mfma >= 0)
+                std::memcpy(bb.data.data() + m.wcc_mfma + (size_t)9 * 2 * cp * cp, v.data(), sizeof(float) * 3 * cp);
         }
         if (!(w = t.get("up_l2.0.weight", {c, c, 2, 2}))) return GS_ERR_INVALID;
         {

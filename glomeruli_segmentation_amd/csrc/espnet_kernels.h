@@ -638,6 +638,38 @@ __global__ void __launch_bounds__(256) dec3_kernel(const Dec3Args a)
                 *reinterpret_cast<float2 *>(at(a.e, n, o, 2 * y + dy, 2 * x)) = make_float2(up[o][dy][0], up[o][dy][1]);
 }
 
+// up_l2 alone: ConvTranspose2d(classes,classes,2,2) -> BR(classes) on the output of combine_l2_l3.1 when that convolution ran on the
+// matrix cores (twelve classes and more; a.t = its output, CLS planes).  reference: Model.py:373 (337)
+template <int CLS>
+__global__ void __launch_bounds__(256) dec3b_kernel(const Dec3Args a)
+{
+    const int H2 = a.t.H, W2 = a.t.W;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.N * H2 * W2)
+        return;
+    const int x = (int)(idx % W2);
+    const int y = (int)((idx / W2) % H2);
+    const int n = (int)(idx / ((long long)W2 * H2));
+    const int ncls = real_classes<CLS>(a.classes);
+    float s[CLS];
+#pragma unroll
+    for (int k = 0; k < CLS; ++k)
+        s[k] = *at(a.t, n, k, y, x);
+    for (int o = 0; o < ncls; ++o) {   // (a rolled loop, as dec1's: CLS * CLS * 4 weights fetched up front would not fit the registers)
+        float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < CLS; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                t[k] = fmaf(s[i], a.wup[(i * CLS + o) * 4 + k], t[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            t[k] = bn_prelu(t[k], a.bnu, CLS, o);
+        *reinterpret_cast<float2 *>(at(a.e, n, o, 2 * y, 2 * x)) = make_float2(t[0], t[1]);
+        *reinterpret_cast<float2 *>(at(a.e, n, o, 2 * y + 1, 2 * x)) = make_float2(t[2], t[3]);
+    }
+}
+
 // classifier ConvTranspose2d(classes,classes,2,2) -> logits -> first-max argmax -> uint8 mask ->
 // per-class pixel counts, on the output of conv CBR(19+classes,classes,3) (which runs on the matrix
 // cores, a conv_mfma_kernel instantiation).  One thread per 1/2-scale pixel (= a 2x2 block of output pixels).
