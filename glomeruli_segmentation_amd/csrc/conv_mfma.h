@@ -234,11 +234,15 @@ constexpr int F_EPI_PIPE = 16777216;
 constexpr int F_X_NOLOAD = 16;  // GS_DIAG timing experiments only (results are garbage): no activation loads in the loop
 constexpr int F_X_NOLDS = 32;   // GS_DIAG: no LDS weight reads in the loop
 constexpr int F_X_NOEPI = 64;   // GS_DIAG: no epilogue at all
-constexpr int F_X_STAMP2 = 4096;   // GS_DIAG: [wave][64] stamps of the wave's first task: 0 start, 2+2c after the MFMA
-                                   // steps of chunk c, 3+2c after the epilogue that follows chunk c
+constexpr int F_X_STAMP2 = 4096;   // GS_DIAG: [wave][STAMP2_SLOTS] stamps of EVERY task of the wave: 0 kernel start, 1 weights staged;
+                                   // task ti from slot 2 + ti * 2 * NCHUNK: + 2c after the MFMA steps of chunk c, + 2c + 1 after the
+                                   // epilogue that follows chunk c (tools/stamps3.py)
+constexpr int STAMP2_SLOTS = 128;
 constexpr int F_X_STAMP = 128;  // GS_DIAG: per-wave s_memrealtime stamps into a.stamp (start, staged, per-dilation, end)
 constexpr int F_X_NOEPIMEM = 2097152;   // GS_DIAG: the epilogue's arithmetic (and fused MFMAs) but none of its residual loads / output stores
-constexpr int F_X_ALL = F_X_NOLOAD | F_X_NOLDS | F_X_NOEPI | F_X_STAMP | F_X_STAMP2 | F_X_NOEPIMEM;
+constexpr int F_X_RESL2 = 33554432;     // GS_DIAG: the residual loads fall into a wave-private 8 KiB window of the image (cache hits): what their LATENCY costs
+constexpr int F_X_STL2 = 67108864;      // GS_DIAG: likewise the result stores
+constexpr int F_X_ALL = F_X_NOLOAD | F_X_NOLDS | F_X_NOEPI | F_X_STAMP | F_X_STAMP2 | F_X_NOEPIMEM | F_X_RESL2 | F_X_STL2;
 
 // Float layout of a configuration's packed image in the weight blob: [weights NDIL*TAPS*CINP*NROW | BN scale, shift,
 // alpha (3*COUT, twice with F_DUAL) | F_FUSE1X1 table NDIL*NACC*64], rounded up to whole float4s.
@@ -269,11 +273,54 @@ constexpr ConvImage conv_image(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT
 // F_RES_RING: the register ring holds 1 / CFG_RES_RING_DIV of a slot's residual values (2: 24 registers spilled in the
 // fused level-3 ESP kernel, 0.190 ms; 4: no spill but the residual latency shows, 0.192 ms)
 #ifndef CFG_RES_RING_DIV
-#define CFG_RES_RING_DIV 2
+#define CFG_RES_RING_DIV 1   // round 6: with the 13-step operand ring (CFG_L3_RING) a whole slot's residual fits (196 registers): requested at
+                             // the top of its dilation (CFG_RES_TOP), no refill inside the epilogue
+#endif
+// Wave priority inside a branch kernel's epilogue (0 = leave the task's priority): the epilogue is a serial stretch in which this
+// wave feeds the matrix pipe next to nothing; at a priority above both task priorities it is through sooner.
+#ifndef CFG_X_EPI
+#define CFG_X_EPI 0   // GS_DIAG timing experiments on the epilogue's memory instructions (results wrong): 1 no residual loads, 2 no result
+                      // stores, 4 residual loads of the even registers only, 8 result stores of the even registers only
+#endif
+// The A operands (weights) of the three horizontal taps of a row group in ONE LDS read.  An LDS read per k-step costs the matrix
+// pipe far more than its own issue slot (tools/micro/kstep_rate.hip: two waves per SIMD, 32x32x2, two matrix instructions per step:
+// 0.85 of the pipe with a ds_read_b32 per step, 0.93-0.95 with one wider read per two / four steps, 0.98 with none), so the branch
+// kernels' weight image is laid out [dilation][tap row][cin][row][tap column] and a lane reads its three values as 12 bytes.
+#ifndef CFG_A_TX3
+#define CFG_A_TX3 0
+#endif
+constexpr bool conv_a_tx3(int TAPS, int NDIL) { return CFG_A_TX3 && TAPS == 9 && NDIL == 5; }
+#ifndef CFG_UNROLL_CHUNKS
+#define CFG_UNROLL_CHUNKS 0
+#endif
+#ifndef CFG_EPI_SPLIT
+#define CFG_EPI_SPLIT 0
+#endif
+#ifndef CFG_RES_TOP
+#define CFG_RES_TOP 1   // round 6: level-2 ESP launch 0.1975 -> 0.194 ms (profiles/r06_ab_combo.txt)
+#endif
+#ifndef CFG_EPI_PRIO
+#define CFG_EPI_PRIO 0
 #endif
 #ifndef CFG_STAGE_ROT
 #define CFG_STAGE_ROT 17   // 0 = every workgroup stages the weight image in the same order
 #endif
+// Depth of the operand ring in k-steps.  A chunk (the unrolled unit, D = G * taps-per-row steps) and the ring used to be the
+// same thing; the ring may be any divisor of the chunk: step u of a chunk lives in slot u % R and is refilled with step u + R
+// (of this chunk, or of the next one).  A shallower ring gives registers back (level 3, two pixels per lane: 3 per step).
+#ifndef CFG_L3_RING
+#define CFG_L3_RING 13   // round 6 (profiles/r06_ab_ring.txt): 3, 13 and 39 steps measure within 1 % of each other once the waits are the
+                         // compiler's exact ones (see the staging barrier below); 13 leaves room for the whole-slot residual prefetch
+#endif
+#ifndef CFG_L2_RING
+#define CFG_L2_RING 27
+#endif
+constexpr int conv_ring_depth(int MT, int TAPS, int NDIL, int P, int G, int FLAGS)
+{
+    return (MT == 32 && TAPS == 9 && NDIL == 5 && (P == 2 || (P == 1 && CFG_L3_RING != 39)) && G == 13) ? CFG_L3_RING
+           : (MT == 16 && TAPS == 9 && NDIL == 5 && P == 4 && G == 9) ? CFG_L2_RING
+                                                                    : G * (TAPS == 9 ? 3 : 1);
+}
 constexpr int conv_min_waves(int MT, int TAPS, int NDIL, int P, int FLAGS)
 {
     return (MT == 16 && TAPS == 9 && NDIL == 5 && P == 4) ? CFG_L2_MINW : 1;
@@ -319,7 +366,12 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
     // and slot of every step are compile-time constants and only G (ty, cin-group) pairs are decoded
     // on the scalar unit per chunk (decoding every step cost ~40 SALU instructions per 4 MFMAs).
     constexpr int RGN = TYN * NSTEP;          // row groups per dilation
-    constexpr int D = G * TXN;                // ring depth = steps per chunk
+    constexpr int D = G * TXN;                // steps per chunk
+    constexpr int R = conv_ring_depth(MT, TAPS, NDIL, P, G, FLAGS);   // ring depth
+    constexpr bool ATX3 = conv_a_tx3(TAPS, NDIL);
+    constexpr int RA = !ATX3 ? R : (R % 3 == 0 ? R : D);             // ring depth of the A operands (ATX3: whole row groups)
+    static_assert(!ATX3 || (TXN == 3 && D % RA == 0 && RA % 3 == 0 && !(FLAGS & (F_S2PAIR | F_S2_FLIP | F_EPI_PIPE))), "A_TX3 is for the branch kernels");
+    static_assert(D % R == 0 && (R == D || !(FLAGS & (F_S2PAIR | F_BNLOAD | F_EPI_PIPE))), "the ring divides the chunk");
     constexpr int CPD = RGN / G;              // chunks per dilation
     constexpr int NCHUNK = NDIL * CPD;
     static_assert(CINP % KL == 0, "k-steps must tile");
@@ -333,7 +385,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     unsigned long long tstamp0 = 0;
-    if (FLAGS & F_X_STAMP)
+    if (FLAGS & (F_X_STAMP | F_X_STAMP2))
         tstamp0 = __builtin_amdgcn_s_memrealtime();
     // LDS image = the blob image (conv_image) from float LDS_SRC0 on: everything, or with F_A_GLOBAL only what follows
     // the weights
@@ -394,7 +446,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
 
     // operand ring (see below); it lives across tasks: the last chunk of a task refills it with the first
     // chunk of the wave's NEXT task, so only a wave's very first loads are exposed
-    float aq[D], bq[S2P ? 1 : D][P];
+    float aq[RA], bq[S2P ? 1 : R][P];
     float bl[S2P ? G : 1][P][3];   // F_S2PAIR: per row group, the inputs 2x-1, 2x, 2x+1 of every pixel
 
     for (int task = t0; task < t1 || !staged; task += tstride) {
@@ -467,10 +519,11 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         // fused 1x1 the kernel has no room for a whole slot (16 x P registers) beside its two accumulator sets.
         constexpr int RR = !RES ? 1 : (FLAGS & F_RES_RING) ? M::NACC / CFG_RES_RING_DIV : M::NACC;
         float resv[RR][P];
+        constexpr bool RES_TOP = RES && RR == M::NACC && CFG_RES_TOP;
         auto load_res = [&](int di, int r) {   // residual values of accumulator register r of concat slot di
             if (!RES)
                 return;
-            if (FLAGS & F_X_NOEPIMEM) {
+            if ((FLAGS & F_X_NOEPIMEM) || (kDiag && ((CFG_X_EPI & 1) || ((CFG_X_EPI & 4) && (r & 1))))) {
 #pragma unroll
                 for (int p = 0; p < P; ++p)
                     resv[r % RR][p] = __builtin_bit_cast(float, di + r + p);
@@ -482,7 +535,10 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             const bool live = ch0 + kq * KSTR < nout;
             const int sr = (cb + ch0) * a.res_sc * 4 + sres;
             if (VEC) {
-                buf_load_vec<P, RAUX>(rres, live ? vr[0] : OOB, sr, resv[r % RR]);
+                if (FLAGS & F_X_RESL2)
+                    buf_load_vec<P, RAUX>(rres, live ? ((int)(wg & 255) * 8192 + ((vr[0] + sr) & 0x1ff0)) : OOB, 0, resv[r % RR]);
+                else
+                    buf_load_vec<P, RAUX>(rres, live ? vr[0] : OOB, sr, resv[r % RR]);
                 return;
             }
 #pragma unroll
@@ -533,16 +589,16 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             if (FLAGS & F_X_NOLOAD) {
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    bq[g * TXN + tx][p] = __builtin_bit_cast(float, soff + p);
+                    bq[(g * TXN + tx) % R][p] = __builtin_bit_cast(float, soff + p);
                 return;
             }
             if (VEC) {
-                buf_load_vec<P, IAUX>(rs, voff, soff, bq[S2P ? 0 : g * TXN + tx]);
+                buf_load_vec<P, IAUX>(rs, voff, soff, bq[S2P ? 0 : (g * TXN + tx) % R]);
                 return;
             }
 #pragma unroll
             for (int p = 0; p < P; ++p)
-                bq[g * TXN + tx][p] = __builtin_bit_cast(
+                bq[(g * TXN + tx) % R][p] = __builtin_bit_cast(
                     float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + p * MT * STRIDE * 4, soff, IAUX));
         };
         auto fetch_pair = [&](const __amdgpu_buffer_rsrc_t &rs, int sb, int c, int g, bool fl) {
@@ -560,21 +616,47 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                 bl[g][p][2] = __builtin_bit_cast(float, e2);
             }
         };
+        // ATX3: the three horizontal taps of row group g of chunk c, one 12-byte read
+        typedef float f32x3a __attribute__((ext_vector_type(3), aligned(4)));
+        auto fetch_a3 = [&](int c, int g) {
+            const int di = c / CPD;
+            int ty0, sidx;
+            decode_rg(c - di * CPD, g, ty0, sidx);
+            const int row0 = ((di * 3 + ty0) * CINP + sidx * KL) * NROW;
+            float v0, v1, v2;
+            if (FLAGS & F_X_NOLDS) {
+                v0 = __builtin_bit_cast(float, row0 + lbase);
+                v1 = v0;
+                v2 = v0;
+            } else if (AGL) {
+                const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(rsrc_w, lbase * 12, row0 * 12, 0);
+                const unsigned e0 = v[0], e1 = v[1], e2 = v[2];
+                v0 = __builtin_bit_cast(float, e0);
+                v1 = __builtin_bit_cast(float, e1);
+                v2 = __builtin_bit_cast(float, e2);
+            } else {
+                const f32x3a v = *reinterpret_cast<const f32x3a *>(lds + (row0 + lbase) * 3);
+                v0 = v[0];
+                v1 = v[1];
+                v2 = v[2];
+            }
+            aq[(g * 3 + 0) % RA] = v0;
+            aq[(g * 3 + 1) % RA] = v1;
+            aq[(g * 3 + 2) % RA] = v2;
+        };
         auto fetch_a = [&](int c, int g, int tx, bool fl) {
             const int di = c / CPD;
             int ty0, sidx;
             decode_rg(c - di * CPD, g, ty0, sidx);
             const int ty = S2FLIP && fl ? TYN - 1 - ty0 : ty0;
             const int tap = TAPS == 9 ? ty * 3 + tx : TAPS == 3 ? ty : 0;
-            if (FLAGS & F_X_NOLDS) {
-                aq[g * TXN + tx] = __builtin_bit_cast(float, tap + sidx + lbase);
+            if ((FLAGS & F_X_NOLDS) && staged)   // (timing only: the ring keeps the values of the task's first chunk -- no instruction at all)
                 return;
-            }
             if (AGL)
-                aq[g * TXN + tx] = __builtin_bit_cast(
+                aq[(g * TXN + tx) % R] = __builtin_bit_cast(
                     float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_w, lbase * 4, (((di * TAPS + tap) * CINP + sidx * KL) * NROW) * 4, 0));
             else
-                aq[g * TXN + tx] = lds[((di * TAPS + tap) * CINP + sidx * KL) * NROW + lbase];
+                aq[(g * TXN + tx) % R] = lds[((di * TAPS + tap) * CINP + sidx * KL) * NROW + lbase];
         };
 
         // F_BNLOAD: the three parameters of this lane's channel in row group g of chunk c (task row yy); one group ahead
@@ -632,7 +714,8 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                 }
 #pragma unroll
                 for (int tx = 0; tx < TXN; ++tx)
-                    fetch_b(rsrc, sbase, c_first, g, tx, flip);
+                    if (g * TXN + tx < R)
+                        fetch_b(rsrc, sbase, c_first, g, tx, flip);
             }
         }
         if (!staged) {
@@ -645,11 +728,24 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             const int rot = (int)((blockIdx.x * (unsigned)CFG_STAGE_ROT) % (unsigned)(pieces > 0 ? pieces : 1));
             for (int j0 = wid; j0 < pieces; j0 += WAVES) {
                 const int j = j0 + rot < pieces ? j0 + rot : j0 + rot - pieces;
+#if defined(CFG_X_STAGE_PLAIN)
+                *reinterpret_cast<f32x4 *>(lds + j * 256 + lane * 4) = *reinterpret_cast<const f32x4 *>(a.wpack + LDS_SRC0 + j * 256 + lane * 4);
+#else
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void *)(a.wpack + LDS_SRC0 + j * 256 + lane * 4),
                     (__attribute__((address_space(3))) void *)(lds + j * 256), 16, 0, 0);
+#endif
             }
+            // The barrier (with the `s_waitcnt vmcnt(0) lgkmcnt(0)` in front of it) is UNCONDITIONAL on this path: an LDS-DMA
+            // instruction is a FLAT operation to the compiler's wait-count pass, and while one may be pending on ANY path into a
+            // block every wait in that block is forced to vmcnt(0) / lgkmcnt(0).  Behind `if (pieces > 0)` the path without the
+            // wait kept "a FLAT operation may be pending" alive around the whole task loop: every chunk began with a full drain
+            // of the operand ring, and the epilogue's first residual use with another (round 6; tools/explore: the assembly of
+            // both builds).  Same registers, same bits; measured the same speed at a 39-step ring (profiles/r06_ab_waitfix.txt), but
+            // the ring and residual experiments of rounds 1-5 were all measured UNDER those forced drains.
+#if defined(CFG_X_BARRIER_COND)
             if (pieces > 0)
+#endif
                 __syncthreads();
             staged = true;
         }
@@ -659,6 +755,14 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             a.stamp[wg * 8 + 0] = tstamp0;
             a.stamp[wg * 8 + 1] = __builtin_amdgcn_s_memrealtime();
         }
+        if ((FLAGS & F_X_STAMP2) && lane == 0 && task == t0) {
+            a.stamp[wg * STAMP2_SLOTS + 0] = tstamp0;
+            a.stamp[wg * STAMP2_SLOTS + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+        // F_X_STAMP2: first slot of this task (tasks beyond the slots are not stamped)
+        const int ti_ = (FLAGS & F_X_STAMP2) ? (task - t0) / tstride : 0;
+        const bool stamp2 = (FLAGS & F_X_STAMP2) && lane == 0 && 2 + (ti_ + 1) * 2 * NCHUNK <= STAMP2_SLOTS;
+        const long long sbase2 = wg * STAMP2_SLOTS + 2 + ti_ * 2 * NCHUNK;
         // optional stagger: the two waves that share a SIMD run the same program on equal-sized tasks
         // and would otherwise reach their epilogues (no MFMA issue) together
         if (kDiag && a.stagger > 0 && task == t0) {
@@ -670,8 +774,13 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int tx = 0; tx < TXN; ++tx)
-                    fetch_a(c_first, g, tx, flip);
+                for (int tx = 0; tx < TXN; ++tx) {
+                    if (ATX3) {
+                        if (tx == 0 && g * 3 < RA)
+                            fetch_a3(c_first, g);
+                    } else if (g * TXN + tx < R)
+                        fetch_a(c_first, g, tx, flip);
+                }
         }
 
         if (BNL) {   // the task's first row group is transformed here, in one piece (once per ~150 k cycles)
@@ -684,7 +793,8 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                 for (int t = 0; t < 3; ++t)
                     bnl_apply(bt[0][p][t], bl[0][p][t], tsc, tsh, tal, tpin, t == 0 && p == 0 && x0 == 0 && px == 0);
         }
-        prefetch_res(0);
+        if (!RES_TOP)
+            prefetch_res(0);
         if (FUSE) {
 #pragma unroll
             for (int p = 0; p < P; ++p)
@@ -702,6 +812,12 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
 
         // One accumulator register (channel row r of both k-groups) of concat slot di on its way out: + residual, BN, PReLU,
         // store(s), the fused 1x1's matrix instructions.  `src` is the accumulator itself or (F_EPI_PIPE) its snapshot.
+        // SPLIT: a slot's outputs are kept (osave) and the fused 1x1's matrix instructions run in one piece behind the slot's
+        // arithmetic and memory instructions.  Interleaved register by register (the round-2 form), every one of them waited for
+        // a free slot of the matrix pipe -- which the SIMD's other wave keeps busy -- in the middle of a serial stretch of LDS reads
+        // and VALU work: an epilogue took 5-7 us, during which that other wave alone could not keep the pipe busy.
+        constexpr bool SPLIT = FUSE && CFG_EPI_SPLIT && !EPI_PIPED;
+        float osave[SPLIT ? M::NACC : 1][P];
         auto epi_reg = [&](int di, auto r_, const typename M::acc_t *src, bool refill_next) __attribute__((always_inline)) {
             constexpr int r = decltype(r_)::value;
             const int nout = di == 0 ? NOUT1 : NOUT;
@@ -710,7 +826,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             const bool live = ch0 + kq * KSTR < nout;
             // (read at the top of the register's step, not inside the uniform branch around its MFMAs: the LDS
             // latency then runs under the BN / PReLU arithmetic instead of in front of the matrix instructions)
-            const float a2 = FUSE ? tab[(di * M::NACC + r) * 64 + lane] : 0.0f;
+            const float a2 = (FUSE && !SPLIT) ? tab[(di * M::NACC + r) * 64 + lane] : 0.0f;
             const int so = (cb + ch0) * a.out_sc * 4 + sout;
             const int so2 = DUAL ? (a.out2_coff + cb + ch0) * a.out2_sc * 4 + sout2 : 0;
             float scale = 1.0f, shift = 0.0f, alpha = 1.0f, scale2 = 1.0f, shift2 = 0.0f, alpha2 = 1.0f;
@@ -756,16 +872,34 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             }
             if (RES && refill_next && di + 1 < NDIL)   // F_EPI_PIPE: register r's residual of the NEXT slot, a dilation ahead of its use
                 load_res(di + 1, r);
-            if (VEC && STORE1 && !(FLAGS & F_X_NOEPIMEM))
-                buf_store_vec<P, SAUX>(rout, live ? vo[0] + so : OOB, o1);
+            if (VEC && STORE1 && !(FLAGS & F_X_NOEPIMEM) && !(kDiag && ((CFG_X_EPI & 2) || ((CFG_X_EPI & 8) && (r & 1)))))
+                buf_store_vec<P, SAUX>(rout, live ? ((FLAGS & F_X_STL2) ? ((int)(wg & 255) * 8192 + ((vo[0] + so) & 0x1ff0)) : vo[0] + so) : OOB, o1);
             if (VEC && DUAL)
                 buf_store_vec<P, SAUX2>(rout2, live ? vo2[0] + so2 : OOB, o2);
             if (FUSE && ch0 < nout) {   // (uniform) registers whose two channels are both beyond the slot hold nothing
                 // k = lane's k-group <-> channel cb + ch0 + kq*KSTR; the table row is zero for channels beyond the slot
 #pragma unroll
-                for (int p = 0; p < P; ++p)
-                    acc2[p] = M::run(a2, o1[p], acc2[p]);
+                for (int p = 0; p < P; ++p) {
+                    if (SPLIT)
+                        osave[SPLIT ? r : 0][p] = o1[p];
+                    else
+                        acc2[p] = M::run(a2, o1[p], acc2[p]);
+                }
             }
+        };
+        // SPLIT: the fused 1x1's matrix instructions of a whole slot, after the slot's arithmetic, loads and stores (same
+        // accumulation order per accumulator: registers 0, 1, 2, ...)
+        auto epi_fused = [&](int di) __attribute__((always_inline)) {
+            static_for<M::NACC>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                const int nout = di == 0 ? NOUT1 : NOUT;
+                if (M::row(r, 0) < nout) {
+                    const float a2 = tab[(di * M::NACC + r) * 64 + lane];
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        acc2[p] = M::run(a2, osave[SPLIT ? r : 0][p], acc2[p]);
+                }
+            });
         };
         typename M::acc_t snap[EPI_PIPED ? P : 1];   // F_EPI_PIPE: the accumulator as the previous dilation left it
 #if defined(GS_DIAG) && defined(CFG_X_S2_EXTRA)
@@ -777,6 +911,9 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         }
 #endif
 
+#if CFG_UNROLL_CHUNKS
+#pragma unroll
+#endif
         for (int c = 0; c < NCHUNK; ++c) {
             if (NDIL > 1 && c % CPD == 0 && prio_mode == 0) {
                 // The two waves of a SIMD run the same program; arbitration prefers the older one, which
@@ -787,6 +924,12 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                 else
                     __builtin_amdgcn_s_setprio(0);
             }
+            // RES_TOP: a slot's residual is requested at the top of its own dilation (a dilation of k-steps ahead of the epilogue that
+            // adds it) instead of at the end of the previous slot's epilogue: the same distance, but the values are no longer carried
+            // around the loop -- the compiler rotated them through a second register set with a copy and an `s_waitcnt vmcnt(0)` at
+            // every dilation boundary
+            if (RES_TOP && c % CPD == 0)
+                prefetch_res(c / CPD);
             if (c % CPD == 0 && c < 2 * CPD) {   // d1 and d2 start fresh; d4, d8, d16 keep adding (HFF)
 #pragma unroll
                 for (int p = 0; p < P; ++p)
@@ -827,8 +970,8 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                     if (u % CFG_X_MFMA_KEEP != 0) {
 #pragma unroll
                         for (int p = 0; p < P; ++p) {
-                            const float bv = S2P ? bl[S2P ? g : 0][p][S2P ? tx : 0] : bq[S2P ? 0 : u][p];
-                            asm volatile("" ::"v"(bv), "v"(aq[u]));
+                            const float bv = S2P ? bl[S2P ? g : 0][p][S2P ? tx : 0] : bq[S2P ? 0 : u % R][p];
+                            asm volatile("" ::"v"(bv), "v"(aq[u % RA]));
                         }
                     } else
 #endif
@@ -842,14 +985,14 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                         if (ty0x >= 1 && tx >= 1) {
 #pragma unroll
                             for (int p = 0; p < P; ++p)
-                                xacc[p] = M::run(aq[u], bt[BNL ? g & 1 : 0][p][S2P ? tx : 0], xacc[p]);
+                                xacc[p] = M::run(aq[u % RA], bt[BNL ? g & 1 : 0][p][S2P ? tx : 0], xacc[p]);
                         }
                     }
 #endif
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
-                        acc[p] = M::run(aq[u], BNL ? bt[BNL ? g & 1 : 0][p][S2P ? tx : 0]
-                                                   : S2P ? bl[S2P ? g : 0][p][S2P ? tx : 0] : bq[S2P ? 0 : u][p], acc[p]);
+                        acc[p] = M::run(aq[u % RA], BNL ? bt[BNL ? g & 1 : 0][p][S2P ? tx : 0]
+                                                       : S2P ? bl[S2P ? g : 0][p][S2P ? tx : 0] : bq[S2P ? 0 : u % R][p], acc[p]);
                         if (ahead) {   // element e = tx*P + p of the next group: (pixel e / 3, tap e % 3)
                             const int e = tx * P + p;
                             if (e < 3 * P)
@@ -866,18 +1009,33 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                                 epi_reg(c - 1, r_, snap, true);
                         });
                     }
-                    if (!S2P)
-                        fetch_b(rs, sb, nx, g, tx, fl);
-                    else if (tx == 2)
-                        fetch_pair(rs, sb, nx, g, fl);
-                    fetch_a(nx, g, tx, fl);
+                    // the slot just consumed is refilled with the step R later: of this chunk, or of the next one
+                    if (R < D && u + R < D) {
+                        fetch_b(rsrc, sbase, c, (u + R) / TXN, (u + R) % TXN, flip);
+                        if (!ATX3)
+                            fetch_a(c, (u + R) / TXN, (u + R) % TXN, flip);
+                    } else {
+                        const int gn = R < D ? (u + R - D) / TXN : g, txn = R < D ? (u + R - D) % TXN : tx;
+                        if (!S2P)
+                            fetch_b(rs, sb, nx, gn, txn, fl);
+                        else if (tx == 2)
+                            fetch_pair(rs, sb, nx, g, fl);
+                        if (!ATX3)
+                            fetch_a(nx, gn, txn, fl);
+                    }
+                    if (ATX3 && tx == 2) {   // the row group just consumed makes room for the one RA / 3 groups later
+                        if (g + RA / 3 < G)
+                            fetch_a3(c, g + RA / 3);
+                        else
+                            fetch_a3(nx, g + RA / 3 - G);
+                    }
                     // pin the ring order: left alone, hipcc sinks the refill loads to the end of the
                     // chunk, which shrinks the prefetch distance from D steps to a few
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if ((FLAGS & F_X_STAMP2) && lane == 0 && task == t0)
-                a.stamp[wg * 64 + 2 + 2 * c] = __builtin_amdgcn_s_memrealtime();
+            if (stamp2)
+                a.stamp[sbase2 + 2 * c] = __builtin_amdgcn_s_memrealtime();
             if ((c + 1) % CPD != 0)
                 continue;
             if (FLAGS & F_X_NOEPI) {
@@ -937,12 +1095,27 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
             }
             // Branch-free epilogue: addresses are (uniform per accumulator register, in an SGPR) + (one
             // per-lane offset), so the whole slot is straight-line VALU + buffer stores.
+#if CFG_EPI_PRIO
+            __builtin_amdgcn_s_setprio(CFG_EPI_PRIO);
+#endif
             static_for<M::NACC>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
-                if ((FLAGS & F_X_STAMP2) && lane == 0 && task == t0 && r < 4)
-                    a.stamp[wg * 64 + 34 + di * 4 + r] = __builtin_amdgcn_s_memrealtime();
                 epi_reg(di, r_, acc, false);
             });
+#if defined(GS_DIAG) && defined(CFG_X_STAMP_A)
+            if (stamp2)   // (diagnostic: the epilogue's end stamp BEFORE the fused matrix instructions)
+                a.stamp[sbase2 + 2 * c + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+            if (SPLIT) {
+                __builtin_amdgcn_sched_barrier(0);   // (or the scheduler interleaves the two phases again)
+                epi_fused(di);
+            }
+#if CFG_EPI_PRIO
+            if (prio_mode == 1 && ((((task - t0) / tstride) + (wid >= WAVES / 2 ? 1 : 0)) & 1))
+                __builtin_amdgcn_s_setprio(1);
+            else
+                __builtin_amdgcn_s_setprio(0);
+#endif
 #if defined(GS_DIAG) && defined(CFG_X_S2_EXTRA)
             if (BNL) {   // keep the second set live; it would be stored as 20 more planes (5 classes x 4 level-2 pixels)
                 float keep = 0.0f;
@@ -975,12 +1148,14 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                         buf_store_vec<P, 0>(rout3, live3 ? vo3[0] + so3 : OOB, o3);
                 }
             }
-            if (RR == M::NACC && di + 1 < NDIL)
+            if (!RES_TOP && RR == M::NACC && di + 1 < NDIL)
                 prefetch_res(di + 1);
             if ((FLAGS & F_X_STAMP) && lane == 0 && task == t0)
                 a.stamp[wg * 8 + 2 + di] = __builtin_amdgcn_s_memrealtime();
-            if ((FLAGS & F_X_STAMP2) && lane == 0 && task == t0)
-                a.stamp[wg * 64 + 3 + 2 * c] = __builtin_amdgcn_s_memrealtime();
+#if !(defined(GS_DIAG) && defined(CFG_X_STAMP_A))
+            if (stamp2)
+                a.stamp[sbase2 + 2 * c + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
         }
     }
 }

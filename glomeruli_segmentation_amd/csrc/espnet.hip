@@ -180,13 +180,17 @@ static bool fold_bn(WeightTable &t, const std::string &bn, const std::string &ac
     return true;
 }
 
-// conv weight [cout][cin][k][k] -> LDS image rows [tap][cin_padded][nrow] of dilation slot `slot`
-static void pack_conv(const float *w, int cout, int cin, int k, float *dst, int slot, int taps, int cinp, int nrow)
+// conv weight [cout][cin][k][k] -> LDS image rows [tap][cin_padded][nrow] of dilation slot `slot`; tx3 (conv_a_tx3: the branch
+// kernels): [tap row][cin_padded][nrow][tap column], a lane's three horizontal taps side by side
+static void pack_conv(const float *w, int cout, int cin, int k, float *dst, int slot, int taps, int cinp, int nrow, bool tx3 = false)
 {
     for (int tap = 0; tap < taps; ++tap)
         for (int ci = 0; ci < cin; ++ci)
-            for (int co = 0; co < cout; ++co)
-                dst[(((size_t)slot * taps + tap) * cinp + ci) * nrow + co] = w[((size_t)co * cin + ci) * k * k + tap];
+            for (int co = 0; co < cout; ++co) {
+                const size_t at = tx3 ? ((((size_t)slot * 3 + tap / 3) * cinp + ci) * nrow + co) * 3 + tap % 3
+                                      : (((size_t)slot * taps + tap) * cinp + ci) * nrow + co;
+                dst[at] = w[((size_t)co * cin + ci) * k * k + tap];
+            }
 }
 
 // `next` names the block whose c1 (1x1 reduce of THIS block's output, Model.py:193) is computed in this block's epilogue
@@ -229,7 +233,7 @@ static bool pack_block(WeightTable &t, BlobBuilder &bb, const std::string &pre, 
         const float *w = t.get(pre + dn[di] + ".conv.weight", {co, n, 3, 3});
         if (!t.ok)
             return false;
-        pack_conv(w, co, n, 3, bb.data.data() + pc.br, di, 9, rcinp, n1);
+        pack_conv(w, co, n, 3, bb.data.data() + pc.br, di, 9, rcinp, n1, conv_a_tx3(9, 5));
     }
     if (pc.fused_next) {
         // table[di][r][lane]: the A operand of the k-step "accumulator register r of slot di": lane = (k-group, c1 output
@@ -438,6 +442,7 @@ static inline unsigned blocks_for(long long items) { return (unsigned)((items + 
 #define GS_DIAG_TRY(call) \
     do {                  \
     } while (0)
+#define GS_DIAG_STAMPED(var, path, ca, ...)
 #endif
 
 template <int CLS>
@@ -535,6 +540,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             {
                 if (small2)
                     return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2, CFG_L2_BR_P2S>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
+                GS_DIAG_STAMPED(162, "gpurun_out/stamps_l2down.txt", with_fused(ca, m->r2[rd2 ^ 1], 12), F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2 | F_VEC, CFG_L2_BR_P4)
                 return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2 | EPIPE_L2_DOWN, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
             }
             return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
@@ -567,11 +573,13 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             if (last) {
                 if (small2)
                     return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2, CFG_L2_BR_P2S>(with_dual(ca, 0), m->num_cus, s);
+                GS_DIAG_STAMPED(163, "gpurun_out/stamps_l2last.txt", with_dual(ca, 0), F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2 | F_VEC, CFG_L2_BR_P4)
                 return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2 | EPIPE_L2_ESP, CFG_L2_BR_P4>(with_dual(ca, 0), m->num_cus, s);
             }
             if (fuse_next) {
                 if (small2)
                     return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | FUSE_L2, CFG_L2_BR_P2S>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
+                GS_DIAG_STAMPED(161, "gpurun_out/stamps_l2esp.txt", with_fused(ca, m->r2[rd2 ^ 1], 12), F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | FUSE_L2 | F_VEC, CFG_L2_BR_P4)
                 return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | FUSE_L2 | EPIPE_L2_ESP, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
             }
             return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
@@ -607,6 +615,7 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             // tasks (batch 1: 64 -> 256 tasks, 0.180 -> see profiles/r04_latency.json)
             if ((long long)n * H3 * cdiv(W3, 128) * 4 <= (long long)m->num_cus * 8)
                 return launch_conv_mfma<CFG_L3_C1S_BNL_P1, F_S2PAIR | POL_L3_C1S | S2FLIP_L3 | F_BNLOAD>(ca, m->num_cus, s);
+            GS_DIAG_STAMPED(165, "gpurun_out/stamps_l3c1s.txt", ca, F_S2PAIR | POL_L3_C1S | S2FLIP_L3 | F_BNLOAD, CFG_L3_C1S_BNL)
             return launch_conv_mfma<CFG_L3_C1S_BNL, F_S2PAIR | POL_L3_C1S | S2FLIP_L3 | F_BNLOAD>(ca, m->num_cus, s);
         }
         return launch_conv_mfma<CFG_L3_C1S, F_S2PAIR | POL_L3_C1S | AGL_S2 | S2FLIP_L3>(conv_args(m->a1, wb + m->l3_0.c1, m->r3[0], nullptr, n), m->num_cus, s);
@@ -616,9 +625,14 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
         if (m->l3_0.fused_next) {   // no residual here: the four-pixel vector mapping still fits with the second accumulator set
             if (small3)
                 return launch_conv_mfma<CFG_L3_BR_P1R, F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3 | SKIP_L3 | (CFG_SMALL_AGL ? F_A_GLOBAL : 0)>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+#if CFG_L3_W16 & 4
+            return launch_conv_mfma<CFG_L3_BR_W16, F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3 | SKIP_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+#endif
 #if CFG_L3_DOWN_P2
-            if (ca.W % 2 == 0 && !no_vec())
+            if (ca.W % 2 == 0 && !no_vec()) {
+                GS_DIAG_STAMPED(164, "gpurun_out/stamps_l3down.txt", with_fused(ca, m->r3[rd3 ^ 1], 25), F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3 | F_VEC | SKIP_L3, CFG_L3_BR_P2R)
                 return launch_conv_mfma<CFG_L3_BR_P2R, F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3 | F_VEC | SKIP_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+            }
 #endif
             if (ca.W % 4 == 0 && !no_vec())
                 return launch_conv_mfma<CFG_L3_BR, F_BNACT | POL_L3_DOWN | AGL_L3 | FUSE_L3 | F_VEC>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
@@ -645,6 +659,9 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             if (fuse_next) {
                 if (small3)   // (one pixel per lane: a whole slot's residual fits in registers, requested a dilation ahead)
                     return launch_conv_mfma<CFG_L3_BR_P1R, F_BNACT | F_RES | POL_L3_ESP | AGL_L3 | FUSE_L3 | SKIP_L3 | (CFG_SMALL_AGL ? F_A_GLOBAL : 0)>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+#if CFG_L3_W16 & 1
+                return launch_conv_mfma<CFG_L3_BR_W16, F_BNACT | F_RES | POL_L3_ESP | AGL_L3 | FUSE_L3 | SKIP_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+#endif
 #if CFG_L3_FUSE_P4
                 // four pixels per lane with the residual through a half-slot register ring (round 2's first fused form)
                 if (ca.W % 4 == 0 && !no_vec())
@@ -654,12 +671,19 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
                 // ring.  A task is then half a row, so the 256 waves of an XCD have TWO images in flight instead of four
                 // and the reduced maps the taps re-read stay in that XCD's 4 MiB L2: beyond-L2 fetch of a launch
                 // 542 -> 296 MB, 0.1898 -> 0.1834 ms (profiles/README.md).
-                if (ca.W % 2 == 0 && !no_vec())
+                if (ca.W % 2 == 0 && !no_vec()) {
+                    if (i == 1) {
+                        GS_DIAG_STAMPED(160, "gpurun_out/stamps_l3esp.txt", with_fused(ca, m->r3[rd3 ^ 1], 25), F_BNACT | F_RES | F_RES_RING | F_VEC | POL_L3_ESP | AGL_L3 | FUSE_L3 | SKIP_L3, CFG_L3_BR_P2R)
+                    }
                     return launch_conv_mfma<CFG_L3_BR_P2R, F_BNACT | F_RES | F_RES_RING | F_VEC | POL_L3_ESP | AGL_L3 | FUSE_L3 | SKIP_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
+                }
                 return launch_conv_mfma<CFG_L3_BR_P2F, F_BNACT | F_RES | AGL_L3 | FUSE_L3>(with_fused(ca, m->r3[rd3 ^ 1], 25), m->num_cus, s);
             }
             if (small3)
                 return launch_conv_mfma<CFG_L3_BR_P1R, F_BNACT | F_RES | POL_L3_ESP | AGL_L3 | SKIP_L3 | (CFG_SMALL_AGL ? F_A_GLOBAL : 0)>(ca, m->num_cus, s);
+#if CFG_L3_W16 & 2
+            return launch_conv_mfma<CFG_L3_BR_W16, F_BNACT | F_RES | POL_L3_ESP | AGL_L3 | SKIP_L3>(ca, m->num_cus, s);
+#endif
 #if CFG_L3_LAST_P2
             // the last (unfused) block in the half-row task shape of the fused ones, tap rows in the halo skipped
             if (ca.W % 2 == 0 && !no_vec())

@@ -51,6 +51,14 @@ namespace gs {
                            // SIMD, up to 4 tiles -- eight tiles took 0.904 ms instead of 0.873, six 0.856 instead of 0.817)
 #endif
 #define CFG_L3_BR_P1R    32, 8,   26,  9,   1,     5,   28,   25,   1, 13
+// experiment (round 6): sixteen waves per workgroup = four per SIMD (<= 128 registers), 32-pixel tasks
+#ifndef CFG_L3_W16
+#define CFG_L3_W16 0      // bit 0: the fused ESP launches, bit 1: the last ESP launch, bit 2: the down-sampler
+#endif
+#ifndef L3W
+#define L3W 16
+#endif
+#define CFG_L3_BR_W16    32, L3W, 26,  9,   1,     5,   28,   25,   1, 13
 #define CFG_L3_C1S_BNL_P1 32, 8,  132, 9,   2,     1,   25,   25,   1, L3C1S_BNL_G
 #define CFG_DEC_CONV     16, 8,   24,  9,   1,     1,   5,    5,    8, 3
 #define CFG_DEC_CONV_XM  16, 8,   24,  3,   1,     1,   5,    5,    8, 6
@@ -149,8 +157,11 @@ constexpr int EPIPE_L2_ESP = (CFG_L2_EPI_PIPE & 1) ? F_EPI_PIPE : 0, EPIPE_L2_DO
 #ifndef POL_L3_DOWN
 #define POL_L3_DOWN 0
 #endif
+#ifndef CFG_L3_XFLAGS
+#define CFG_L3_XFLAGS 0   // -DGS_DIAG ablation builds: F_X_NOEPI / F_X_NOLOAD / F_X_NOLDS / F_X_NOEPIMEM ORed into the level-3 ESP launches
+#endif
 #ifndef POL_L3_ESP
-#define POL_L3_ESP F_RES_NT
+#define POL_L3_ESP (F_RES_NT | CFG_L3_XFLAGS)
 #endif
 #ifndef POL_L2_C1
 #define POL_L2_C1 0
