@@ -15,12 +15,12 @@ if os.environ.get("GLOMSEG_LIB") and os.environ.get("GLOMSEG_EXPERIMENT") == "1"
 GS_OK = 0
 GS_IN_U8_BGR_NHWC = 0
 GS_IN_F32_NCHW = 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 GS_BUILD_DIAG = 1
 MAX_CROPS_PER_CALL = 64
 
 STATUS_NAMES = {0: "GS_OK", 1: "GS_ERR_INVALID", 2: "GS_ERR_HIP", 3: "GS_ERR_NOMEM", 4: "GS_ERR_UNSUPPORTED",
-                5: "GS_ERR_NODEVICE"}
+                5: "GS_ERR_NODEVICE", 6: "GS_ERR_DEVICE_FAULT"}
 
 
 class GlomsegError(RuntimeError):
@@ -63,6 +63,7 @@ PROTOTYPES = {
     "gs_last_error": (ctypes.c_char_p, []),
     "gs_abi_version": (_I, []),
     "gs_build_flags": (_I, []),
+    "gs_device_fault_check": (_I, []),
     "gs_espnet_create": (_I, [_P, ctypes.POINTER(LayerDesc), _I, _I, _I, _I, _I, ctypes.POINTER(_P)]),
     "gs_espnet_destroy": (None, [_P]),
     "gs_espnet_reserve": (_I, [_P, _I, _I, _I]),

@@ -759,9 +759,11 @@ gs_status gs_espnet_segment_crops_host(gs_espnet *const *models, int n_models, c
     }
     for (int k = 0; k < NSLOT; ++k)
         drain(p.sl[(slot + k) % NSLOT]);   // oldest first
-    if (rc != GS_OK)
+    if (rc != GS_OK) {
         hipDeviceSynchronize();
-    return rc;
+        return rc;
+    }
+    return gs_device_fault_check();
 }
 
 }  // extern "C"

@@ -23,6 +23,9 @@
 namespace gs {
 
 
+// set by a wave whose bounded mailbox wait ran out (EXCH below); read and cleared by dec_tail_fault_flags()
+__device__ int g_dec_tail_fault = 0;
+
 template <int N_>
 using IC = std::integral_constant<int, N_>;
 template <bool B_>
@@ -248,12 +251,28 @@ __global__ void __launch_bounds__(WAVES * 64) dec_tail_kernel(const DecTailArgs 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0)
                     __hip_atomic_store(&rows_done[wid], epoch + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (has_left)
-                    for (int spin = 0; __hip_atomic_load(&rows_done[wid - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= epoch && spin < (1 << 22); ++spin)
+                // (bounded, so that a broken protocol cannot hang the GPU -- but a wait that runs out is REPORTED: the values copied
+                // below would be stale, so the wave raises the device-side fault word, which the host entries that synchronise
+                // turn into GS_ERR_DEVICE_FAULT (gs_device_fault_check) instead of returning masks nobody should trust)
+                bool gave_up = false;
+                if (has_left) {
+                    int spin = 0;
+                    while (__hip_atomic_load(&rows_done[wid - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= epoch && spin < (1 << 22)) {
                         __builtin_amdgcn_s_sleep(1);
-                if (has_right)
-                    for (int spin = 0; __hip_atomic_load(&rows_done[wid + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= epoch && spin < (1 << 22); ++spin)
+                        ++spin;
+                    }
+                    gave_up = gave_up || spin >= (1 << 22);
+                }
+                if (has_right) {
+                    int spin = 0;
+                    while (__hip_atomic_load(&rows_done[wid + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= epoch && spin < (1 << 22)) {
                         __builtin_amdgcn_s_sleep(1);
+                        ++spin;
+                    }
+                    gave_up = gave_up || spin >= (1 << 22);
+                }
+                if (gave_up && lane == 0)
+                    atomicOr(&g_dec_tail_fault, 1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 if (ln < 5)
                     tile[ln * TS] = has_left ? mbox[((wid - 1) * 2 + par) * 16 + ln] : 0.0f;

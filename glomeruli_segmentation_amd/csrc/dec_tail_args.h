@@ -38,5 +38,9 @@ constexpr int DT_PACK_FLOATS = DT_A_FLOATS + 16 + 100;
 
 // conv CBR(19+classes, classes, 3) + classifier deconvolution + argmax + counts in one or two launches (dec_tail.h)
 gs_status launch_dec_tail(DecTailArgs a, int num_cus, hipStream_t stream);
+// The exchanging form's mailbox waits are bounded; a wave that gives one up sets a device-side fault word instead of going on
+// silently with values it did not receive.  Reads AND clears that word (the caller has synchronised the work it asks about);
+// *flags != 0: results of dec_tail launches since the last call are not to be trusted.
+gs_status dec_tail_fault_flags(int *flags);
 
 }  // namespace gs

@@ -893,7 +893,19 @@ using namespace gs;
 extern "C" {
 
 const char *gs_last_error(void) { return g_err.c_str(); }
-int gs_abi_version(void) { return 4; }   // 2: lanes, block hook, detector, compositor LUT; 3: batched crop entries, detector host entry, build flags; 4: any class count 2..20 (hist is [n,classes]), batch planner, pinned-block query, overlays from the crop pipeline
+int gs_abi_version(void) { return 5; }   // 2: lanes, block hook, detector, compositor LUT; 3: batched crop entries, detector host entry, build flags; 4: any class count 2..20 (hist is [n,classes]), batch planner, pinned-block query, overlays from the crop pipeline; 5: gs_device_fault_check, GS_ERR_DEVICE_FAULT
+gs_status gs_device_fault_check(void)
+{
+    GS_HIP(hipDeviceSynchronize());
+    int flags = 0;
+    gs_status st = dec_tail_fault_flags(&flags);
+    if (st != GS_OK) return st;
+    if (flags) {
+        set_error("device fault word %d: a decoder-tail wave gave up its strip-boundary exchange; the results of the calls since the last check are invalid", flags);
+        return GS_ERR_DEVICE_FAULT;
+    }
+    return GS_OK;
+}
 int gs_build_flags(void)
 {
 #ifdef GS_DIAG
@@ -1617,9 +1629,11 @@ gs_status gs_espnet_segment_host(gs_espnet *h, const uint8_t *tiles, int n_tiles
     }
     for (int k = 0; k < NSLOT; ++k)
         drain(sl[(slot + k) % NSLOT]);   // oldest first
-    if (rc != GS_OK)
+    if (rc != GS_OK) {
         hipDeviceSynchronize();
-    return rc;
+        return rc;
+    }
+    return gs_device_fault_check();   // (every batch has been drained: a few microseconds)
 }
 
 }  // extern "C"

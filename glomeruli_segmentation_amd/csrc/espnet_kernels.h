@@ -342,6 +342,19 @@ __device__ __forceinline__ int real_classes(int classes)
 {
     return CLS == 5 ? 5 : classes;   // (folds away on the fast path)
 }
+// The padded lanes of a class vector are zero only as long as every activation that met their zero weights was finite:
+// 0 * inf = NaN would sit in a padding lane and -- through the deconvolutions below, which mix ALL input lanes into every
+// output class -- reach the real classes, where an exact-width kernel (and the reference) would confine a non-finite value to
+// the classes that actually use it.  So the lanes beyond the model's count are re-zeroed in front of every such mixing chain.
+template <int CLS>
+__device__ __forceinline__ void zero_padding_lanes(float *s, int ncls)
+{
+    if constexpr (CLS != 5) {
+#pragma unroll
+        for (int k = 0; k < CLS; ++k)
+            s[k] = k < ncls ? s[k] : 0.0f;
+    }
+}
 // floats per channel record [scale, shift, alpha, w[0..CLS)] of dec1, and per weight row of dec2: whole float4s
 template <int CLS>
 constexpr int dec1_record() { return (3 + CLS + 3) / 4 * 4; }
@@ -434,6 +447,7 @@ __global__ void __launch_bounds__(256) dec1_kernel(const Dec1Args a)
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = s[k] * a.br[k] + a.br[CLS + k];
+    zero_padding_lanes<CLS>(s, ncls);
     if constexpr (CLS != 5) {
         // one output class at a time (a rolled loop): unrolled, the CLS * CLS * 4 weights were all fetched up front -- 1 600
         // registers' worth at twenty classes, 4 KB of scratch per lane
@@ -617,6 +631,7 @@ __global__ void __launch_bounds__(256) dec3_kernel(const Dec3Args a)
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = bn_prelu(s[k], a.bnc, CLS, k);
+    zero_padding_lanes<CLS>(s, ncls);
     float up[CLS][2][2];
 #pragma unroll
     for (int o = 0; o < CLS; ++o)
@@ -655,6 +670,7 @@ __global__ void __launch_bounds__(256) dec3b_kernel(const Dec3Args a)
 #pragma unroll
     for (int k = 0; k < CLS; ++k)
         s[k] = *at(a.t, n, k, y, x);
+    zero_padding_lanes<CLS>(s, ncls);
     for (int o = 0; o < ncls; ++o) {   // (a rolled loop, as dec1's: CLS * CLS * 4 weights fetched up front would not fit the registers)
         float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -729,6 +745,7 @@ __global__ void __launch_bounds__(256) dec4_kernel(const Dec4Args a)
 #pragma unroll
         for (int k = 0; k < CLS; ++k)
             s[q][k] = *at(a.f, n, k, ys[q], xs[q]);
+        zero_padding_lanes<CLS>(s[q], ncls);
     }
 #pragma unroll
     for (int q = 0; q < DEC4_PX; ++q) {

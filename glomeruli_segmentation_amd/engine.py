@@ -110,6 +110,13 @@ class EspnetEngine:
             st.synchronize()
         torch.cuda.current_stream(self.device).synchronize()
 
+    def check_device_faults(self):
+        """Synchronise the device and raise if a kernel of an earlier stream-ordered call (segment / forward_logits / lanes) reported
+        through the device-side fault word that it went on without data it was waiting for (gs_device_fault_check; the host
+        pipelines check by themselves).  Cheap: one device synchronise and a 4-byte read."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.gs_device_fault_check())
+
     def close(self):
         if getattr(self, "handle", None):
             with torch.cuda.device(self.device):

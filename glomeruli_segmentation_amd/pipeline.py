@@ -20,8 +20,14 @@ from .composite import SlideCompositor
 from .shard import all_reduce_any, rank_range
 
 
+def engine_classes(engine):
+    """class count of an engine or of an ensemble (list of engines: the members agree, engine.segment_crops checks)"""
+    e = engine[0] if isinstance(engine, (list, tuple)) else engine
+    return int(e.classes)
+
+
 def segment_crops(engine, crops, mean, std, net_h, net_w, batch=32, paste=None, origins=None, want_masks=True):
-    """crops: list of uint8 BGR [h,w,3] arrays of any size -> (list of uint8 class maps [h,w], counts int64 [n,5]) through
+    """crops: list of uint8 BGR [h,w,3] arrays of any size -> (list of uint8 class maps [h,w], counts int64 [n,classes]) through
     the library's batched crop pipeline (gs_espnet_segment_crops_host); with `paste` (+ origins) the maps are also
     max-composited into the slide map on the GPU, in the same launches."""
     r = engine.segment_crops(crops, mean, std, net_h, net_w, batch, want_masks=want_masks, paste=paste, origins=origins)
@@ -33,7 +39,7 @@ def run_slide(engine, read_region, slide_w, slide_h, mpp_x, mpp_y, detector, mea
               net_h=512, net_w=1024, rank=0, world=1, dist=None, batch=32, detector_batch=1):
     """read_region(x, y, w, h, downsample) -> uint8 RGB [h,w,3] of the slide at that downsample (level-0 origin).
     Returns dict(boxes=merged boxes, masks=this rank's crop masks, map=1/8 class map (rank 0 / all ranks when
-    dist is None), counts=per-class pixel totals over all crops)."""
+    dist is None), counts=per-class pixel totals over all crops: int64 [engine.classes])."""
     dev = engine.device
     level, ds = detect.pick_level(objective_power, level_downsamples)
     plan = detect.plan_windows(slide_w, slide_h, mpp_x, mpp_y, ds, window_um, overlap)
@@ -57,7 +63,8 @@ def run_slide(engine, read_region, slide_w, slide_h, mpp_x, mpp_y, detector, mea
     if crops:     # resample, forward, resize back, count and paste: one pipeline call for the rank's crops
         masks, cnt = segment_crops(engine, crops, mean, std, net_h, net_w, batch, paste=comp.paste_target(),
                                    origins=[(b[0], b[1]) for b in boxes[lo:hi]])
-    counts = torch.zeros(5, dtype=torch.int64, device=dev)
+    # one bin per class of the MODEL (VisualizeResults_iou.py:151-156 counts `args.classes` values, :315 passes them on)
+    counts = torch.zeros(engine_classes(engine), dtype=torch.int64, device=dev)
     if cnt is not None:
         counts += torch.from_numpy(cnt.sum(0)).to(dev)
     if dist is not None and world > 1:

@@ -104,7 +104,13 @@ def abort_rank(dist):
     this returns, i.e. in single-process runs: a device synchronise after a GPU fault may never come back), leave with status 1
     (a SystemExit's own non-zero code is kept) -- at once, without
     interpreter shutdown (a process-group destructor may itself wait for the peers).  With one rank the exception just
-    propagates."""
+    propagates.
+
+    EVERY exit from inside the sharded region is a failure of the job, a `SystemExit(0)`, `SystemExit(None)` or
+    `SystemExit("message")` included: the rank's peers are in (or on their way to) a collective that this rank will now
+    never join, so there is no "clean early finish" of one rank -- a rank that has nothing to do takes part in the exchange
+    with an empty range instead (rank_range).  Those exits therefore leave with status 1 as well (and their traceback),
+    which is what makes launch.spawn_ranks end the peers; only a non-zero integer code is passed through unchanged."""
     if dist is None:
         return
     import os
@@ -146,13 +152,15 @@ def reduce_sum_to_all(array, dist, device=None):
     return t.cpu().numpy()
 
 
-def segment_sharded(compute, load_tiles, total, rank, world, dist=None, device=None, batch=32, classes=5,
+def segment_sharded(compute, load_tiles, total, rank, world, dist=None, device=None, batch=32, classes=None,
                     gather_masks=True):
     """Run `compute` over this rank's tile range and do the final exchange.
 
     compute(tiles uint8 [n,H,W,3]) -> (masks uint8 [n,H,W], counts int64 [n,classes])  (numpy or torch)
     load_tiles(lo, hi) -> uint8 [hi-lo,H,W,3] for global tile indices [lo, hi)
     Returns (masks [total,H,W] on rank 0 else None, counts_total int64 [classes] on every rank).
+    `classes` = the model's class count (Model.py:311; engine.classes); None takes it from the counts `compute` returns -- a rank
+    whose range is empty then learns it from the other ranks (a MAX all-reduce) before the totals are summed.
 
     Masks that `compute` returns as device tensors stay on the device: they are concatenated there and handed to
     the collective as they are (backend "nccl" = RCCL: GPU to GPU over xGMI); only the gathered result on rank 0
@@ -169,16 +177,27 @@ def segment_sharded(compute, load_tiles, total, rank, world, dist=None, device=N
         m = m if isinstance(m, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(m))
         c = c if isinstance(c, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(c))
         masks.append(m)
+        if classes is None:
+            if c.dim() != 2:
+                raise ValueError("segment_sharded: compute must return counts [n, classes] when `classes` is not given")
+            classes = int(c.shape[1])
         csum = c.reshape(-1, classes).sum(0).to(torch.int64)
         counts = csum if counts is None else counts + csum
     local = torch.cat(masks, 0) if masks else None
-    if counts is None:
-        counts = torch.zeros(classes, dtype=torch.int64)
     if dist is None:      # (a process group of one rank still runs the exchange: the nccl test executes it on one GPU)
+        if counts is None:
+            counts = torch.zeros(classes or 0, dtype=torch.int64)
         return (local.cpu().numpy() if local is not None else None), counts.cpu().numpy()
     # gloo takes host tensors; every other backend (nccl = RCCL) takes tensors on this rank's GPU -- also from a rank whose
     # range is empty or whose compute returned host arrays
     dev = collective_device(dist, device)
+    ncls = torch.tensor([classes or 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(ncls, op=dist.ReduceOp.MAX)          # ranks with an empty range take the class count from the others
+    if classes is not None and int(ncls[0]) != classes:
+        raise ValueError("segment_sharded: ranks disagree about the class count (%d here, %d elsewhere)" % (classes, int(ncls[0])))
+    classes = int(ncls[0])
+    if counts is None:
+        counts = torch.zeros(classes, dtype=torch.int64)
     tot = counts.to(dev)
     dist.all_reduce(tot)                                   # per-class pixel totals of the whole slide
     out = None

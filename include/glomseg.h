@@ -33,7 +33,8 @@ typedef enum gs_status {
     GS_ERR_HIP = 2,         /* a HIP runtime call failed */
     GS_ERR_NOMEM = 3,
     GS_ERR_UNSUPPORTED = 4, /* configuration the kernels are not built for */
-    GS_ERR_NODEVICE = 5     /* no gfx950 device visible */
+    GS_ERR_NODEVICE = 5,    /* no gfx950 device visible */
+    GS_ERR_DEVICE_FAULT = 6 /* a kernel reported, through the device-side fault word, that it went on without data it was waiting for */
 } gs_status;
 
 const char *gs_last_error(void);
@@ -43,6 +44,13 @@ int gs_abi_version(void);
  * construction can be switched on through the environment); the product library returns 0 and reads no environment. */
 #define GS_BUILD_DIAG 1
 int gs_build_flags(void);
+/* Synchronises the current device, then reads and clears the device-side fault word: GS_ERR_DEVICE_FAULT when a kernel of an
+ * earlier call gave up a bounded wait (the decoder tail's strip-boundary exchange) and went on with stale values -- the masks,
+ * counts and logits of calls since the previous check are then not to be used.  The host pipelines (gs_espnet_segment_host,
+ * gs_espnet_segment_crops_host) make this check themselves before they return; callers of the stream-ordered entries
+ * (gs_espnet_forward*, gs_espnet_segment_crops, gs_espnet_ensemble_*) call it where they synchronise.  No reference
+ * counterpart (cuDNN has no such exchange); ABI 5. */
+gs_status gs_device_fault_check(void);
 
 /* ------------------------------------------------------------------ weights
  * One entry per state_dict tensor, named exactly as in models/espnet_fold*.pth
@@ -170,7 +178,11 @@ gs_status gs_espnet_ensemble_segment_crops(gs_espnet *const *models, int n_model
 /* Optional overlay output of the host pipeline below (VisualizeResults_iou.py:139-146): every crop's class map coloured with the
  * palette (rows RGB as in the reference's table, written [b, g, r]) and blended over the crop as
  * cv2.addWeighted(crop, wa, colour, wb, 0) = saturate_cast<uchar>(round(crop * wa + colour * wb)), each product and the sum
- * rounded to fp32 on its own (no fused multiply-add), round-half-to-even: bit for bit what numpy computes.  out_bgr[i] is host
+ * rounded to fp32 on its own (no fused multiply-add), round-half-to-even: bit for bit what numpy computes for that expression
+ * (imageops.add_weighted, the checker of the GPU tests).  NOT pinned against cv2 itself -- OpenCV is not installable in the build
+ * image, and an FMA3 build of its 8u addWeighted may fuse the second product into the sum, which differs from two separately
+ * rounded products on exact ties only (at weights 0.4 / 0.6 a tie needs crop * 0.4f + colour * 0.6f to land on x.5 in fp32).
+ * out_bgr[i] is host
  * uint8 [heights[i], widths[i], 3]; page-locked buffers laid out like the packed input (every crop at the 256-byte-aligned
  * offset behind its batch's first one, in ONE allocation) are written a batch per DMA, anything else crop by crop. */
 #define GS_MAX_PALETTE 64

@@ -9,7 +9,12 @@ from conftest import load_golden, load_weights, random_state_dict
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = 2e-4     # fp32 MFMA vs fp32 reference: only the summation order differs
+# fp32 MFMA vs the fp32 reference: only the summation order differs.  Round 6: 2e-4 -> 5e-5 for everything checked against the
+# fold-1 goldens and the oracle (measured ~5e-6 on the logits, ~1e-6 on encoder stages): a decoder tap bug of 1e-4 must not pass.
+# The random-weight class / depth cases further down keep their 5e-4-relative bound (their logits reach magnitudes of 1e2-1e3).
+LOGIT_TOL = 5e-5
+ENC_STAGE_TOL = 1e-5      # every encoder stage of test_stage_by_stage
+DEC_STAGE_TOL = 5e-5      # its decoder stages (up_l3, up_l2, conv)
 
 
 @pytest.fixture(scope="module")
@@ -49,11 +54,12 @@ def test_stage_by_stage(torch_mod, engine1):
         got = engine1.read_stage(mine)
         assert got.shape == z[ref].shape, mine
         worst[mine] = float(np.abs(got - z[ref]).max())
-    bad = {k: v for k, v in worst.items() if not v <= LOGIT_TOL}
+    # per-stage bounds at what the hardware delivers: a tap address that misses by a row shows up here long before it reaches
+    # the logits' tolerance (the first lazy-b2 build: level3_0 off by 5.6e-5 in its first row)
+    decoder = ("up_l3", "up_l2", "conv")
+    bad = {k: v for k, v in worst.items() if not v <= (DEC_STAGE_TOL if k in decoder else ENC_STAGE_TOL)}
     assert not bad, "stages off: %s (all: %s)" % (bad, worst)
-    # the encoder stages sit two orders of magnitude inside that bound (~1e-6); a tap address that misses by a row shows up
-    # here long before it reaches the logits' tolerance (the first lazy-b2 build: level3_0 off by 5.6e-5 in its first row)
-    assert worst["b2"] <= 1e-5 and worst["level3_0"] <= 1e-5 and worst["level3.7"] <= 1e-5, worst
+    print("stage errors:", {k: "%.2e" % v for k, v in worst.items()})
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
@@ -97,6 +103,7 @@ def test_full_size_masks(torch_mod, fold):
         conf += orc.confusion(mask[s], ref)
     assert orc.present_class_miou(conf) >= 0.999          # the north_star bar
     assert np.trace(conf) / conf.sum() >= 0.9995
+    eng.check_device_faults()     # no decoder-tail wave gave up its strip-boundary exchange (gs_device_fault_check)
     eng.close()
 
 
@@ -1023,6 +1030,71 @@ def test_slide_pipeline_detect_merge_crop_segment_composite(torch_mod, engine1):
     X0, Y0 = -(-b[0] // 8), -(-b[1] // 8)
     sub = alone[(Y0 * 8 - b[1])::8, (X0 * 8 - b[0])::8]
     assert np.array_equal(m[Y0:Y0 + sub.shape[0], X0:X0 + sub.shape[1]], sub)
+
+
+def test_slide_pipeline_with_a_seven_class_model(torch_mod):
+    """`run_slide` takes the class count from the ENGINE (VisualizeResults_iou.py:151-156 counts `args.classes` values, :315
+    passes them through): a random-weight ESPNet(7, 1, 2) -- counts over seven bins == bincount of the returned crop maps, the
+    1/8 map max-composited as for five classes, every class value < 7; and shard.segment_sharded with `classes` taken from the
+    counts `compute` returns.  Round 5 hard-coded five bins here (a shape error for any other model)."""
+    torch = torch_mod
+    from glomeruli_segmentation_amd import detect, pipeline, shard
+    from glomeruli_segmentation_amd.engine import EspnetEngine
+    from glomeruli_segmentation_amd.synth import FOLD_MEAN_STD, synth_tile
+    mean, std = FOLD_MEAN_STD[1]
+    eng = EspnetEngine(random_state_dict(1, 2, classes=7, seed=77), classes=7, p=1, q=2)
+    SW, SH, mpp = 8000, 6000, 0.25
+    canvas = synth_tile(5, SH // 8, SW // 8, blobs=10)[:, :, ::-1].copy()
+    truth = [(900, 700, 1800, 1500), (4200, 800, 5000, 1900), (5600, 3900, 6700, 5000)]
+
+    def read_region(x, y, w, h, ds):
+        ys = np.clip(((y + np.arange(h) * ds) / 8).astype(int), 0, canvas.shape[0] - 1)
+        xs = np.clip(((x + np.arange(w) * ds) / 8).astype(int), 0, canvas.shape[1] - 1)
+        return canvas[ys][:, xs]
+
+    plan = detect.plan_windows(SW, SH, mpp, mpp, 8.0, 2000, 0.1)
+    state = {"i": 0}
+
+    def detector(im):
+        i, j, xs, ys = plan.origins()[state["i"]]
+        state["i"] += 1
+        wx = plan.window_x * plan.downsample
+        inside = [(x1, y1, x2, y2) for (x1, y1, x2, y2) in truth if x1 >= xs and y1 >= ys and x2 <= xs + wx and y2 <= ys + wx]
+        n = len(inside)
+        b = np.zeros((1, max(n, 1), 4), np.float32)
+        sc = np.zeros((1, max(n, 1)), np.float32)
+        for k, (x1, y1, x2, y2) in enumerate(inside):
+            b[0, k] = [(y1 - ys) / wx, (x1 - xs) / wx, (y2 - ys) / wx, (x2 - xs) / wx]
+            sc[0, k] = 0.9
+        return b, sc, np.ones_like(sc), np.array([n])
+
+    res = pipeline.run_slide(eng, read_region, SW, SH, mpp, mpp, detector, mean, std)
+    assert len(res["boxes"]) == len(truth) and len(res["masks"]) == len(truth)
+    counts = res["counts"].cpu().numpy()
+    assert counts.shape == (7,)
+    want = np.zeros(7, dtype=np.int64)
+    for m in res["masks"]:
+        assert m.dtype == np.uint8 and int(m.max()) < 7
+        want += np.bincount(m.ravel(), minlength=7)
+    assert (counts == want).all() and len(np.nonzero(want)[0]) >= 3, want     # (a random net spreads over several classes)
+    # the 1/8 map: max-composite of the crop maps, as for five classes
+    ref = np.zeros((-(-SH // 8), -(-SW // 8)), dtype=np.uint8)
+    for b, m in zip(res["boxes"], res["masks"]):
+        X0, Y0 = -(-b[0] // 8), -(-b[1] // 8)
+        sub = m[(Y0 * 8 - b[1])::8, (X0 * 8 - b[0])::8]
+        ref[Y0:Y0 + sub.shape[0], X0:X0 + sub.shape[1]] = np.maximum(ref[Y0:Y0 + sub.shape[0], X0:X0 + sub.shape[1]], sub)
+    got = res["map"].cpu().numpy()
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    # segment_sharded without a `classes` argument: seven bins from what compute returns
+    tiles = np.stack([synth_tile(40 + i, 64, 128, blobs=3) for i in range(3)])
+
+    def compute(t):
+        mk, hs, _ = eng.segment(torch.from_numpy(np.ascontiguousarray(t)).cuda(), mean, std)
+        return mk, hs
+    masks, tot = shard.segment_sharded(compute, lambda lo, hi: tiles[lo:hi], 3, 0, 1, dist=None, batch=2)
+    assert tot.shape == (7,) and (tot == np.bincount(masks.ravel(), minlength=7)).all()
+    eng.check_device_faults()
+    eng.close()
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -553,9 +553,9 @@ def test_a_rank_that_raises_inside_a_cli_ends_the_job(tmp_path):
     helper = os.path.join(REPO, "tests", "helpers", "detect_stub_rank.py")
     argv = ["--target_list", tl, "--data_dir", data_dir, "--staining", "OPT_PAS", "--output_dir", str(tmp_path / "out"),
             "--window_size", "500", "--overlap_ratio", "0.1", "--batch", "4"]
-    saved = {k: os.environ.get(k) for k in ("GLOMSEG_DIST_BACKEND", "GS_TEST_FAIL_RANK", "MASTER_PORT", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    saved = {k: os.environ.get(k) for k in ("GLOMSEG_DIST_BACKEND", "GS_TEST_FAIL_RANK", "GS_TEST_FAIL_HOW", "MASTER_PORT", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
     try:
-        for k in ("MASTER_PORT", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        for k in ("MASTER_PORT", "WORLD_SIZE", "RANK", "LOCAL_RANK", "GS_TEST_FAIL_HOW"):
             os.environ.pop(k, None)
         os.environ["GLOMSEG_DIST_BACKEND"] = "gloo"
         os.environ["GS_TEST_FAIL_RANK"] = "1"
@@ -565,6 +565,18 @@ def test_a_rank_that_raises_inside_a_cli_ends_the_job(tmp_path):
         el = time.time() - t0
         assert rc == 1 and el < 60.0, (rc, el, err.getvalue()[-800:])
         assert "rank 1 of 2 exited with code 1" in err.getvalue() and "fails on purpose" in err.getvalue()
+        # shard.abort_rank's contract: ANY exit of one rank inside the sharded region fails the job -- SystemExit(0) and
+        # SystemExit("message") leave with status 1 (the peers wait in a collective this rank never joins), a non-zero
+        # integer code is kept
+        for how, want in (("exit0", 1), ("exit_message", 1), ("exit7", 7)):
+            os.environ["GS_TEST_FAIL_HOW"] = how
+            os.environ.pop("MASTER_PORT", None)
+            out, err = io.StringIO(), io.StringIO()
+            t0 = time.time()
+            rc = launch.spawn_ranks(helper, argv, 2, out=out, err=err)
+            assert rc == want and time.time() - t0 < 60.0, (how, rc, err.getvalue()[-800:])
+            assert "rank 1 of 2 exited with code %d" % want in err.getvalue(), (how, err.getvalue()[-800:])
+        os.environ.pop("GS_TEST_FAIL_HOW", None)
         # and the same command line with nobody failing writes the one CSV
         os.environ["GS_TEST_FAIL_RANK"] = "none"
         os.environ.pop("MASTER_PORT", None)

@@ -96,7 +96,7 @@ def main():
     boxes = bench_slide.grid_boxes(S, example)
     mine = list(range(rank, args.slides, world))          # one slide per rank (and the next round of slides after it)
 
-    totals = torch.zeros((args.slides, 5), dtype=torch.int64, device=dev)
+    totals = torch.zeros((args.slides, int(engines[0].classes)), dtype=torch.int64, device=dev)
     t_read = t_gpu = 0.0
     n_crops = 0
     origins = [(b[0], b[1]) for b in boxes]

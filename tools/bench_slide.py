@@ -172,7 +172,7 @@ def main():
     def segment_leg():
         # crop -> resample -> segment -> resize back -> count -> composite: one pipeline call (gs_espnet_segment_crops_host)
         comp = SlideCompositor(S, S, dev)
-        counts = torch.zeros(5, dtype=torch.int64, device=dev)
+        counts = torch.zeros(int(eng.classes), dtype=torch.int64, device=dev)
         if crops:
             _, cnt = segment_crops(eng, crops, mean, std, 512, 1024, 32, paste=comp.paste_target(), origins=[(b[0], b[1]) for b in mine],
                                    want_masks=True)
