@@ -116,6 +116,7 @@ struct ConvArgs {
     int strips;    // pixel strips per output row
     int total_tasks;
     int wu;        // waves of a workgroup that take tasks (launch_conv_mfma: WAVES unless the launch has fewer tasks than wave slots)
+    int rev_n;     // 1: images are taken last to first (the launch reads what its producer wrote most recently first)
 };
 
 typedef unsigned u32x3_t __attribute__((ext_vector_type(3)));
@@ -328,7 +329,7 @@ constexpr int conv_min_waves(int MT, int TAPS, int NDIL, int P, int FLAGS)
 
 #define M_KL_OF(MT_) (Mfma<MT_>::KL)
 template <int MT, int WAVES, int CINP, int TAPS, int STRIDE, int NDIL, int NOUT1, int NOUT, int P, int G, int FLAGS>
-__global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, FLAGS) * WAVES / 8) conv_mfma_kernel(const ConvArgs a)
+__global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TAPS, NDIL, P, FLAGS) * WAVES / 8 : 2) conv_mfma_kernel(const ConvArgs a)
 {
     constexpr bool BNACT = FLAGS & F_BNACT, RES = FLAGS & F_RES, STORE1 = !(FLAGS & F_NOSTORE), DUAL = FLAGS & F_DUAL;
     constexpr bool S2P = FLAGS & F_S2PAIR;
@@ -414,6 +415,9 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
     const int vout2 = DUAL ? (kq * KSTR * a.out2_sc + xl) * 4 : 0;
     const int vout3 = FUSE ? (kq * KSTR * a.out3_sc + xl) * 4 : 0;
     const int prio_mode = kDiag ? a.prio_mode : 1;
+    // the two waves that share a SIMD (their priorities alternate): waves wid and wid + 4 of an eight-wave workgroup; with
+    // four-wave workgroups (two per CU) the SIMD's other wave belongs to the workgroup dispatched half a grid later
+    const bool second_of_simd = WAVES >= 8 ? wid >= WAVES / 2 : blockIdx.x >= gridDim.x / 2;
 
     // Task order is (image, row, strip).  Workgroups that share an XCD (equal blockIdx % 8 under
     // round-robin dispatch: a speed assumption only) own one contiguous eighth of the tasks, and inside
@@ -452,8 +456,9 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
     for (int task = t0; task < t1 || !staged; task += tstride) {
         const bool idle = task >= t1;   // a wave without work still has to help stage the weights
         const int tk = idle ? (a.total_tasks - 1) : task;
-        const int n = tk / tasks_per_img;
-        const int rem = tk - n * tasks_per_img;
+        const int n0_ = tk / tasks_per_img;
+        const int n = a.rev_n ? a.N - 1 - n0_ : n0_;
+        const int rem = tk - n0_ * tasks_per_img;
         // F_SKIP_PAD: rows near the top / bottom edge skip tap rows and finish early, and a wave's tasks are the SAME row of
         // images `img_stride` apart -- so every other group of images has its rows rotated by half the height (a bijection
         // per image): a wave then owns one edge row and one middle row, and the saving is spread over all waves
@@ -468,8 +473,9 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         const int sbase = (a.in_off + y * STRIDE * a.in_pitch + x0 * STRIDE - (XMERGE ? 1 : 0)) * 4;
         // the wave's next task (itself when this is the last one: a harmless redundant prefetch)
         const int tn = task + tstride < t1 ? task + tstride : tk;
-        const int n_n = tn / tasks_per_img;
-        const int rem_n = tn - n_n * tasks_per_img;
+        const int n0n_ = tn / tasks_per_img;
+        const int n_n = a.rev_n ? a.N - 1 - n0n_ : n0n_;
+        const int rem_n = tn - n0n_ * tasks_per_img;
         const int y0r_n = rem_n / a.strips;
         const int y_n = SKIP && ((n_n / img_stride) & 1) ? (y0r_n + yrot >= a.H ? y0r_n + yrot - a.H : y0r_n + yrot) : y0r_n;
         const __amdgpu_buffer_rsrc_t rsrc_n = __builtin_amdgcn_make_buffer_rsrc(
@@ -766,7 +772,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
         // optional stagger: the two waves that share a SIMD run the same program on equal-sized tasks
         // and would otherwise reach their epilogues (no MFMA issue) together
         if (kDiag && a.stagger > 0 && task == t0) {
-            const int ph = wid >= WAVES / 2 ? 1 : 0;   // the second wave of every SIMD starts late
+            const int ph = second_of_simd ? 1 : 0;   // the second wave of every SIMD starts late
             for (int z = 0; z < a.stagger * ph; ++z)
                 __builtin_amdgcn_s_sleep(16);
         }
@@ -801,12 +807,12 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                 acc2[p] = (typename M::acc_t)(0.0f);
         }
         if (prio_mode == 1) {
-            if ((((task - t0) / tstride) + (wid >= WAVES / 2 ? 1 : 0)) & 1)
+            if ((((task - t0) / tstride) + (second_of_simd ? 1 : 0)) & 1)
                 __builtin_amdgcn_s_setprio(1);
             else
                 __builtin_amdgcn_s_setprio(0);
         } else if (prio_mode == 3 && task == t0) {
-            if (wid >= WAVES / 2)
+            if (second_of_simd)
                 __builtin_amdgcn_s_setprio(1);
         }
 
@@ -919,7 +925,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                 // The two waves of a SIMD run the same program; arbitration prefers the older one, which
                 // then finishes its task ~20 % earlier and leaves its partner alone on the pipe.
                 // Alternating static priority per dilation keeps the pair level.
-                if (((c / CPD) + (wid >= WAVES / 2 ? 1 : 0)) & 1)
+                if (((c / CPD) + (second_of_simd ? 1 : 0)) & 1)
                     __builtin_amdgcn_s_setprio(1);
                 else
                     __builtin_amdgcn_s_setprio(0);
@@ -1111,7 +1117,7 @@ __global__ void __launch_bounds__(WAVES * 64, conv_min_waves(MT, TAPS, NDIL, P, 
                 epi_fused(di);
             }
 #if CFG_EPI_PRIO
-            if (prio_mode == 1 && ((((task - t0) / tstride) + (wid >= WAVES / 2 ? 1 : 0)) & 1))
+            if (prio_mode == 1 && ((((task - t0) / tstride) + (second_of_simd ? 1 : 0)) & 1))
                 __builtin_amdgcn_s_setprio(1);
             else
                 __builtin_amdgcn_s_setprio(0);

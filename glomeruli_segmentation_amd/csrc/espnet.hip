@@ -500,7 +500,9 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
     // ---- level 2 (Model.py:351-357): DownSamplerB(19,64) then p ESP blocks
     L.run(K_L2_C1S, px2 * (19 * 9 * 12 * 2), [&] {
         GS_DIAG_TRY(diag_reduce_s2(m, 2, conv_args(m->a0, wb + m->l2_0.c1, m->r2[0], nullptr, n), s, dst_));
-        return launch_conv_mfma<CFG_L2_C1S, F_S2PAIR | POL_L2_C1S | AGL_S2 | S2FLIP_L2>(conv_args(m->a0, wb + m->l2_0.c1, m->r2[0], nullptr, n), m->num_cus, s);
+        ConvArgs ca = conv_args(m->a0, wb + m->l2_0.c1, m->r2[0], nullptr, n);
+        ca.rev_n = CFG_L2_C1S_REV;
+        return launch_conv_mfma<CFG_L2_C1S, F_S2PAIR | POL_L2_C1S | AGL_S2 | S2FLIP_L2>(ca, m->num_cus, s);
     });
     // b2 = BR(131) over cat([output1, output1_0, inp2]) (Model.py:359) never runs as a kernel: the last ESP block stores
     // only its b2-normalised form (planes 0..63 of output1_cat), the pool kernel writes planes 128..130 normalised, and
@@ -540,19 +542,23 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             {
                 if (small2)
                     return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2, CFG_L2_BR_P2S>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
-                GS_DIAG_STAMPED(162, "gpurun_out/stamps_l2down.txt", with_fused(ca, m->r2[rd2 ^ 1], 12), F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2 | F_VEC, CFG_L2_BR_P4)
-                return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2 | EPIPE_L2_DOWN, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
+                GS_DIAG_STAMPED(162, "gpurun_out/stamps_l2down.txt", with_fused(ca, m->r2[rd2 ^ 1], 12), F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2 | F_VEC | SKIP_L2, CFG_L2_BR_P4)
+#if CFG_L2_DOWN_SKIP
+                if (ca.W % L2SP == 0 && !no_vec())   // tap-row chunks, tap rows in the zero halo skipped (espnet_config.h)
+                    return launch_conv_mfma<CFG_L2_BR_P4S, F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2 | F_VEC | F_SKIP_PAD>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
+#endif
+                return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | FUSE_L2 | EPIPE_L2_DOWN | SKIP_L2, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
             }
-            return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
+            return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | SKIP_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
         }
         if (fuse_b2) {
             ca = with_dual(ca, 64);
             GS_DIAG_TRY(diag_l2_down(m, ca, with_fused(conv_args(m->r2[rd2], wb + m->l2_0.br, m->bb[0], nullptr, n), m->r2[rd2 ^ 1], 12), s, dst_));
             if (m->l2_0.fused_next)
-                return launch_vec<F_BNACT | F_DUAL | POL_L2_DOWN | AGL_L2 | FUSE_L2, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
-            return launch_vec<F_BNACT | F_DUAL | POL_L2_DOWN | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
+                return launch_vec<F_BNACT | F_DUAL | POL_L2_DOWN | AGL_L2 | FUSE_L2 | SKIP_L2, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
+            return launch_vec<F_BNACT | F_DUAL | POL_L2_DOWN | AGL_L2 | SKIP_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
         }
-        return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
+        return launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | SKIP_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
     });
     bool have_r2 = m->l2_0.fused_next;   // the reduced map of the next block already exists
     rd2 ^= have_r2 ? 1 : 0;
@@ -573,16 +579,16 @@ static gs_status forward_impl(Model *m, const void *in, int in_format, int n, in
             if (last) {
                 if (small2)
                     return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2, CFG_L2_BR_P2S>(with_dual(ca, 0), m->num_cus, s);
-                GS_DIAG_STAMPED(163, "gpurun_out/stamps_l2last.txt", with_dual(ca, 0), F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2 | F_VEC, CFG_L2_BR_P4)
-                return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2 | EPIPE_L2_ESP, CFG_L2_BR_P4>(with_dual(ca, 0), m->num_cus, s);
+                GS_DIAG_STAMPED(163, "gpurun_out/stamps_l2last.txt", with_dual(ca, 0), F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2 | F_VEC | SKIP_L2, CFG_L2_BR_P4)
+                return launch_vec<F_BNACT | F_RES | F_NOSTORE | F_DUAL | POL_L2_LAST | AGL_L2 | EPIPE_L2_ESP | SKIP_L2, CFG_L2_BR_P4>(with_dual(ca, 0), m->num_cus, s);
             }
             if (fuse_next) {
                 if (small2)
                     return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | FUSE_L2, CFG_L2_BR_P2S>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
-                GS_DIAG_STAMPED(161, "gpurun_out/stamps_l2esp.txt", with_fused(ca, m->r2[rd2 ^ 1], 12), F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | FUSE_L2 | F_VEC, CFG_L2_BR_P4)
-                return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | FUSE_L2 | EPIPE_L2_ESP, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
+                GS_DIAG_STAMPED(161, "gpurun_out/stamps_l2esp.txt", with_fused(ca, m->r2[rd2 ^ 1], 12), F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | FUSE_L2 | F_VEC | SKIP_L2, CFG_L2_BR_P4)
+                return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | FUSE_L2 | EPIPE_L2_ESP | SKIP_L2, CFG_L2_BR_P4>(with_fused(ca, m->r2[rd2 ^ 1], 12), m->num_cus, s);
             }
-            return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
+            return launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | SKIP_L2, CFG_L2_BR_P4>(ca, m->num_cus, s);
         });
         have_r2 = fuse_next;
         rd2 ^= have_r2 ? 1 : 0;
@@ -1390,8 +1396,8 @@ gs_status gs_espnet_block_forward(gs_espnet *h, int kind, int level, int index, 
             r = kind == 1 ? launch_conv_mfma<CFG_L2_C1S, F_S2PAIR | POL_L2_C1S | AGL_S2 | S2FLIP_L2>(conv_args(src, wb + pc.c1, red, nullptr, 1), m.num_cus, s)
                           : launch_conv_mfma<CFG_L2_C1, POL_L2_C1>(conv_args(src, wb + pc.c1, red, nullptr, 1), m.num_cus, s);
             if (r != GS_OK) return r;
-            r = kind == 1 ? launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2, CFG_L2_BR_P4>(conv_args(red, wb + pc.br, dst, nullptr, 1), m.num_cus, s)
-                          : launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2, CFG_L2_BR_P4>(conv_args(red, wb + pc.br, dst, &src, 1), m.num_cus, s);
+            r = kind == 1 ? launch_vec<F_BNACT | (POL_L2_DOWN & F_ST_NT) | AGL_L2 | SKIP_L2, CFG_L2_BR_P4>(conv_args(red, wb + pc.br, dst, nullptr, 1), m.num_cus, s)
+                          : launch_vec<F_BNACT | F_RES | POL_L2_ESP | AGL_L2 | SKIP_L2, CFG_L2_BR_P4>(conv_args(red, wb + pc.br, dst, &src, 1), m.num_cus, s);
         } else {
             r = kind == 1 ? launch_conv_mfma<CFG_L3_C1S, F_S2PAIR | POL_L3_C1S | AGL_S2 | S2FLIP_L3>(conv_args(src, wb + pc.c1, red, nullptr, 1), m.num_cus, s)
                           : launch_conv_mfma<CFG_L3_C1, POL_L3_C1>(conv_args(src, wb + pc.c1, red, nullptr, 1), m.num_cus, s);

@@ -23,7 +23,16 @@ namespace gs {
 #ifndef L2SG
 #define L2SG 9
 #endif
-#define CFG_L2_BR_P4     16, 8,   12,  9,   1,     5,   16,   12,   L2SP, L2SG   // shipped (4, 9): a whole dilation's operands in flight
+#ifndef L2W
+#define L2W 8     // waves per workgroup of the level-2 branch kernels (4: two four-wave workgroups per CU, finer launch tails)
+#endif
+#define CFG_L2_BR_P4     16, L2W, 12,  9,   1,     5,   16,   12,   L2SP, L2SG   // shipped (4, 9): a whole dilation's operands in flight
+// the level-2 down-sampler's branches with a chunk of ONE tap row (nine steps, a nine-step ring) and F_SKIP_PAD: 0.1868 -> 0.1764 ms
+// (profiles/r06_ab_l2g3.txt); the ESP blocks lose with that shape (0.1948 -> 0.2024) and keep the whole-dilation chunk
+#define CFG_L2_BR_P4S    16, L2W, 12,  9,   1,     5,   16,   12,   L2SP, 3
+#ifndef CFG_L2_DOWN_SKIP
+#define CFG_L2_DOWN_SKIP 1
+#endif
 #define CFG_L3_C1S       32, 8,   132, 9,   2,     1,   25,   25,   4, 6
 #ifndef L3C1S_BNL_G
 #define L3C1S_BNL_G 6     // F_BNLOAD form; a deeper ring measured no better (9: 0.192 ms vs 0.189) or spilled (11: 0.287)
@@ -33,7 +42,10 @@ namespace gs {
 #define CFG_L3_BR        32, 8,   26,  9,   1,     5,   28,   25,   4, 3
 #define CFG_L3_BR_P2     32, 8,   26,  9,   1,     5,   28,   25,   2, 13
 #define CFG_L3_BR_P2F    32, 8,   26,  9,   1,     5,   28,   25,   2, 3    // with the fused 1x1: 32 more accumulators
-#define CFG_L3_BR_P2R    32, 8,   26,  9,   1,     5,   28,   25,   2, 13   // shipped fused ESP form: a third of a dilation in flight
+#ifndef L3WB
+#define L3WB 8    // waves per workgroup of the shipped level-3 branch form (4 needs CFG_AGL_L3: two workgroups' weight images do not fit the LDS)
+#endif
+#define CFG_L3_BR_P2R    32, L3WB, 26, 9,   1,     5,   28,   25,   2, 13   // shipped fused ESP form: a third of a dilation in flight
 // small batches (launches with fewer tasks than SIMDs): 32-pixel strips -- the same accumulation chain per pixel, four /
 // two times the tasks (forward_impl picks the shape per launch from the task count; tools/latency.py)
 #ifndef CFG_SMALL_AGL
@@ -111,6 +123,12 @@ constexpr int FUSE_L3 = CFG_FUSE_L3 ? F_FUSE1X1 : 0, FUSE_L2 = CFG_FUSE_L2 ? F_F
 // F_S2_FLIP (odd output rows of the stride-2 reduces walk their tap rows bottom-up, so neighbouring waves fetch the input
 // row they share together): level 3 0.160 -> 0.153 ms, beyond-L2 fetch 910 -> 693 MB; level 2 0.0957 -> 0.0909 ms,
 // 524 -> 430 MB.  On for both.
+// The level-2 stride-2 reduce takes its images last to first: it re-reads the 319 MB the stem has just written, more than the
+// 256 MB Infinity Cache holds, and the images the stem wrote LAST are the ones that may still be there.  Measured in
+// profiles/r06_ab_l2_reduce.txt.
+#ifndef CFG_L2_C1S_REV
+#define CFG_L2_C1S_REV 0
+#endif
 #ifndef CFG_S2_FLIP
 #define CFG_S2_FLIP 3   // bit 0: level-2 stride-2 reduce, bit 1: level-3
 #endif
@@ -121,6 +139,11 @@ constexpr int S2FLIP_L2 = (CFG_S2_FLIP & 1) ? F_S2_FLIP : 0, S2FLIP_L3 = (CFG_S2
 #define CFG_SKIP_PAD 1
 #endif
 constexpr int SKIP_L3 = CFG_SKIP_PAD ? F_SKIP_PAD : 0;
+// ... and at level 2 (needs a chunk of one tap row there too: L2SG = 3; 3.2 % of the level-2 branch k-steps)
+#ifndef CFG_SKIP_PAD_L2
+#define CFG_SKIP_PAD_L2 0
+#endif
+constexpr int SKIP_L2 = CFG_SKIP_PAD_L2 ? F_SKIP_PAD : 0;
 // Lazy b2: b2 = BR(131) over cat([output1, output1_0, inp2]) (Model.py:359) used to be fused into its producers, the
 // down-sampler writing output1_0 TWICE (raw for the level-2 ESP blocks, b2-normalised into planes 64..127 of output1_cat).
 // The normalised copy is now never written: its two consumers -- the level-3 stride-2 reduce (F_IN2: BN + PReLU on the B
