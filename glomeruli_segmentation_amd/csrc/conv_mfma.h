@@ -294,6 +294,9 @@ constexpr bool conv_a_tx3(int TAPS, int NDIL) { return CFG_A_TX3 && TAPS == 9 &&
 #ifndef CFG_UNROLL_CHUNKS
 #define CFG_UNROLL_CHUNKS 0
 #endif
+#ifndef CFG_EPI_PRELOAD
+#define CFG_EPI_PRELOAD 0
+#endif
 #ifndef CFG_EPI_SPLIT
 #define CFG_EPI_SPLIT 0
 #endif
@@ -824,29 +827,48 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
         // and VALU work: an epilogue took 5-7 us, during which that other wave alone could not keep the pipe busy.
         constexpr bool SPLIT = FUSE && CFG_EPI_SPLIT && !EPI_PIPED;
         float osave[SPLIT ? M::NACC : 1][P];
-        auto epi_reg = [&](int di, auto r_, const typename M::acc_t *src, bool refill_next) __attribute__((always_inline)) {
+        // the per-register constants of an epilogue step: BN scale / shift / PReLU slope of the lane's channel (twice with F_DUAL)
+        // and the fused 1x1's A operand
+        struct EpiParams {
+            float scale = 1.0f, shift = 0.0f, alpha = 1.0f, scale2 = 1.0f, shift2 = 0.0f, alpha2 = 1.0f, a2 = 0.0f;
+        };
+        auto epi_params = [&](int di, auto r_) __attribute__((always_inline)) {
+            constexpr int r = decltype(r_)::value;
+            const int nout = di == 0 ? NOUT1 : NOUT;
+            const int cb = di == 0 ? 0 : NOUT1 + (di - 1) * NOUT;
+            const int ch0 = M::row(r, 0);
+            const bool live = ch0 + kq * KSTR < nout;
+            EpiParams q;
+            // (read at the top of the register's step, not inside the uniform branch around its MFMAs: the LDS
+            // latency then runs under the BN / PReLU arithmetic instead of in front of the matrix instructions)
+            q.a2 = (FUSE && !SPLIT) ? tab[(di * M::NACC + r) * 64 + lane] : 0.0f;
+            if (BNACT) {
+                const float *bp = bnp + (live ? cb + ch0 + kq * KSTR : 0);
+                q.scale = bp[0];
+                q.shift = bp[COUT];
+                q.alpha = bp[2 * COUT];
+                if (DUAL) {
+                    q.scale2 = bp[3 * COUT];
+                    q.shift2 = bp[4 * COUT];
+                    q.alpha2 = bp[5 * COUT];
+                }
+            }
+            return q;
+        };
+        // EPI_PRELOAD (few accumulator registers: the 16x16x4 forms): a slot's constants are all requested up front -- read register
+        // by register, each of the four steps began with three or four LDS reads and a wait for them
+        constexpr bool EPI_PRELOAD = CFG_EPI_PRELOAD && M::NACC <= 4 && !EPI_PIPED;
+        auto epi_reg = [&](int di, auto r_, const typename M::acc_t *src, bool refill_next, const EpiParams *pre = nullptr) __attribute__((always_inline)) {
             constexpr int r = decltype(r_)::value;
             const int nout = di == 0 ? NOUT1 : NOUT;
             const int cb = di == 0 ? 0 : NOUT1 + (di - 1) * NOUT;
             const int ch0 = M::row(r, 0);   // channel held by k-group 0; group kq holds ch0 + kq*KSTR
             const bool live = ch0 + kq * KSTR < nout;
-            // (read at the top of the register's step, not inside the uniform branch around its MFMAs: the LDS
-            // latency then runs under the BN / PReLU arithmetic instead of in front of the matrix instructions)
-            const float a2 = (FUSE && !SPLIT) ? tab[(di * M::NACC + r) * 64 + lane] : 0.0f;
+            const EpiParams q = pre ? pre[r] : epi_params(di, r_);
+            const float a2 = q.a2;
             const int so = (cb + ch0) * a.out_sc * 4 + sout;
             const int so2 = DUAL ? (a.out2_coff + cb + ch0) * a.out2_sc * 4 + sout2 : 0;
-            float scale = 1.0f, shift = 0.0f, alpha = 1.0f, scale2 = 1.0f, shift2 = 0.0f, alpha2 = 1.0f;
-            if (BNACT) {
-                const float *bp = bnp + (live ? cb + ch0 + kq * KSTR : 0);
-                scale = bp[0];
-                shift = bp[COUT];
-                alpha = bp[2 * COUT];
-                if (DUAL) {
-                    scale2 = bp[3 * COUT];
-                    shift2 = bp[4 * COUT];
-                    alpha2 = bp[5 * COUT];
-                }
-            }
+            const float scale = q.scale, shift = q.shift, alpha = q.alpha, scale2 = q.scale2, shift2 = q.shift2, alpha2 = q.alpha2;
             float o1[P], o2[P];
             const float pin = prelu_pin(alpha), pin2 = prelu_pin(alpha2);
 #pragma unroll
@@ -1104,10 +1126,13 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
 #if CFG_EPI_PRIO
             __builtin_amdgcn_s_setprio(CFG_EPI_PRIO);
 #endif
-            static_for<M::NACC>([&](auto r_) {
-                constexpr int r = decltype(r_)::value;
-                epi_reg(di, r_, acc, false);
-            });
+            if constexpr (EPI_PRELOAD) {
+                EpiParams pre[M::NACC];
+                static_for<M::NACC>([&](auto r_) { pre[decltype(r_)::value] = epi_params(di, r_); });
+                static_for<M::NACC>([&](auto r_) { epi_reg(di, r_, acc, false, pre); });
+            } else {
+                static_for<M::NACC>([&](auto r_) { epi_reg(di, r_, acc, false); });
+            }
 #if defined(GS_DIAG) && defined(CFG_X_STAMP_A)
             if (stamp2)   // (diagnostic: the epilogue's end stamp BEFORE the fused matrix instructions)
                 a.stamp[sbase2 + 2 * c + 1] = __builtin_amdgcn_s_memrealtime();
