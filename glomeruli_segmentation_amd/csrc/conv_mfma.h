@@ -294,6 +294,9 @@ constexpr bool conv_a_tx3(int TAPS, int NDIL) { return CFG_A_TX3 && TAPS == 9 &&
 #ifndef CFG_UNROLL_CHUNKS
 #define CFG_UNROLL_CHUNKS 0
 #endif
+#ifndef CFG_REFILL_MID
+#define CFG_REFILL_MID 0
+#endif
 #ifndef CFG_EPI_PRELOAD
 #define CFG_EPI_PRELOAD 0
 #endif
@@ -373,6 +376,13 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
     constexpr int D = G * TXN;                // steps per chunk
     constexpr int R = conv_ring_depth(MT, TAPS, NDIL, P, G, FLAGS);   // ring depth
     constexpr bool ATX3 = conv_a_tx3(TAPS, NDIL);
+    // REFILL_MID: the refill of a ring slot is issued BETWEEN the matrix instructions of the NEXT step (behind the first half of
+    // them) instead of behind all of its own step's: a wave issues in order, so `mfma, mfma, load, ds_read, scalar work` leaves
+    // everything but the matrix instructions to the one window behind the second of them; with the refill in the middle both windows
+    // are used.  The slot refilled is the previous step's (its own step's B registers are still to be read), so the ring holds R - 1
+    // steps ahead.
+    constexpr bool MID = CFG_REFILL_MID && TAPS == 9 && NDIL == 5 && P >= 2 && !(FLAGS & (F_S2PAIR | F_BNLOAD | F_EPI_PIPE)) && !ATX3;
+    constexpr int RB = MID ? 1 : 0;   // steps by which the refill lags
     constexpr int RA = !ATX3 ? R : (R % 3 == 0 ? R : D);             // ring depth of the A operands (ATX3: whole row groups)
     static_assert(!ATX3 || (TXN == 3 && D % RA == 0 && RA % 3 == 0 && !(FLAGS & (F_S2PAIR | F_S2_FLIP | F_EPI_PIPE))), "A_TX3 is for the branch kernels");
     static_assert(D % R == 0 && (R == D || !(FLAGS & (F_S2PAIR | F_BNLOAD | F_EPI_PIPE))), "the ring divides the chunk");
@@ -595,12 +605,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
             const int ty = S2FLIP && fl ? TYN - 1 - ty0 : ty0;
             const int toff = TAPS == 9 ? ((ty - 1) * a.in_pitch + (tx - 1)) << di : TAPS == 3 ? (ty - 1) * a.in_pitch : 0;
             const int soff = sb + (toff + sidx * KL * a.in_sc) * 4;
-            if (FLAGS & F_X_NOLOAD) {
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    bq[(g * TXN + tx) % R][p] = __builtin_bit_cast(float, soff + p);
+            if ((FLAGS & F_X_NOLOAD) && staged)   // (timing only: the ring keeps the values of the task's first chunk -- no instruction at all)
                 return;
-            }
             if (VEC) {
                 buf_load_vec<P, IAUX>(rs, voff, soff, bq[S2P ? 0 : (g * TXN + tx) % R]);
                 return;
@@ -723,7 +729,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
                 }
 #pragma unroll
                 for (int tx = 0; tx < TXN; ++tx)
-                    if (g * TXN + tx < R)
+                    if (g * TXN + tx < R - RB)
                         fetch_b(rsrc, sbase, c_first, g, tx, flip);
             }
         }
@@ -787,7 +793,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
                     if (ATX3) {
                         if (tx == 0 && g * 3 < RA)
                             fetch_a3(c_first, g);
-                    } else if (g * TXN + tx < R)
+                    } else if (g * TXN + tx < R - RB)
                         fetch_a(c_first, g, tx, flip);
                 }
         }
@@ -973,6 +979,23 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
             const __amdgpu_buffer_rsrc_t rs = last ? rsrc_n : rsrc;
             const int sb = last ? sbase_n : sbase;
             const bool fl = last ? flip_n : flip;
+            // refill of the ring slot that step u (MID: step u - 1) of this chunk has just left: the step R (R - 1) later
+            auto refill = [&](int u) __attribute__((always_inline)) {
+                const int v = u + R - RB;
+                if (v < D && (R < D || MID)) {
+                    fetch_b(rsrc, sbase, c, v / TXN, v % TXN, flip);
+                    if (!ATX3)
+                        fetch_a(c, v / TXN, v % TXN, flip);
+                } else {
+                    const int gn = (v - D) / TXN, txn = (v - D) % TXN;
+                    if (!S2P)
+                        fetch_b(rs, sb, nx, gn, txn, fl);
+                    else if (txn == 2)
+                        fetch_pair(rs, sb, nx, gn, fl);
+                    if (!ATX3)
+                        fetch_a(nx, gn, txn, fl);
+                }
+            };
             if (!SKIP || chunk_live(y, c)) {
 #pragma unroll
             for (int g = 0; g < G; ++g)
@@ -1021,6 +1044,11 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
                     for (int p = 0; p < P; ++p) {
                         acc[p] = M::run(aq[u % RA], BNL ? bt[BNL ? g & 1 : 0][p][S2P ? tx : 0]
                                                        : S2P ? bl[S2P ? g : 0][p][S2P ? tx : 0] : bq[S2P ? 0 : u % R][p], acc[p]);
+                        if (MID && p == P / 2 - 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            refill(u);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         if (ahead) {   // element e = tx*P + p of the next group: (pixel e / 3, tap e % 3)
                             const int e = tx * P + p;
                             if (e < 3 * P)
@@ -1038,19 +1066,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
                         });
                     }
                     // the slot just consumed is refilled with the step R later: of this chunk, or of the next one
-                    if (R < D && u + R < D) {
-                        fetch_b(rsrc, sbase, c, (u + R) / TXN, (u + R) % TXN, flip);
-                        if (!ATX3)
-                            fetch_a(c, (u + R) / TXN, (u + R) % TXN, flip);
-                    } else {
-                        const int gn = R < D ? (u + R - D) / TXN : g, txn = R < D ? (u + R - D) % TXN : tx;
-                        if (!S2P)
-                            fetch_b(rs, sb, nx, gn, txn, fl);
-                        else if (tx == 2)
-                            fetch_pair(rs, sb, nx, g, fl);
-                        if (!ATX3)
-                            fetch_a(nx, gn, txn, fl);
-                    }
+                    if (!MID)
+                        refill(u);
                     if (ATX3 && tx == 2) {   // the row group just consumed makes room for the one RA / 3 groups later
                         if (g + RA / 3 < G)
                             fetch_a3(c, g + RA / 3);

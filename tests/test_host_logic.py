@@ -520,6 +520,7 @@ def test_cabi_argument_and_device_errors_without_gpu(sd1):
     if not torch.cuda.is_available():
         rc = lib.gs_espnet_create(blob.ctypes.data_as(ctypes.c_void_p), table, len(table), 5, 2, 8, 0, ctypes.byref(h))
         assert rc in (2, 5), rc                                                              # GS_ERR_HIP / GS_ERR_NODEVICE: loud, no fallback
+        assert lib.gs_device_fault_check() == 2 and lib.gs_last_error()                      # no device to synchronise: GS_ERR_HIP, not "no fault"
         from glomeruli_segmentation_amd.engine import EspnetEngine
         with pytest.raises(RuntimeError):
             EspnetEngine(sd1)
