@@ -283,17 +283,6 @@ constexpr ConvImage conv_image(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT
 #define CFG_X_EPI 0   // GS_DIAG timing experiments on the epilogue's memory instructions (results wrong): 1 no residual loads, 2 no result
                       // stores, 4 residual loads of the even registers only, 8 result stores of the even registers only
 #endif
-// The A operands (weights) of the three horizontal taps of a row group in ONE LDS read.  An LDS read per k-step costs the matrix
-// pipe far more than its own issue slot (tools/micro/kstep_rate.hip: two waves per SIMD, 32x32x2, two matrix instructions per step:
-// 0.85 of the pipe with a ds_read_b32 per step, 0.93-0.95 with one wider read per two / four steps, 0.98 with none), so the branch
-// kernels' weight image is laid out [dilation][tap row][cin][row][tap column] and a lane reads its three values as 12 bytes.
-#ifndef CFG_A_TX3
-#define CFG_A_TX3 0
-#endif
-constexpr bool conv_a_tx3(int TAPS, int NDIL) { return CFG_A_TX3 && TAPS == 9 && NDIL == 5; }
-#ifndef CFG_UNROLL_CHUNKS
-#define CFG_UNROLL_CHUNKS 0
-#endif
 #ifndef CFG_REFILL_MID
 #define CFG_REFILL_MID 0
 #endif
@@ -375,16 +364,14 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
     constexpr int RGN = TYN * NSTEP;          // row groups per dilation
     constexpr int D = G * TXN;                // steps per chunk
     constexpr int R = conv_ring_depth(MT, TAPS, NDIL, P, G, FLAGS);   // ring depth
-    constexpr bool ATX3 = conv_a_tx3(TAPS, NDIL);
     // REFILL_MID: the refill of a ring slot is issued BETWEEN the matrix instructions of the NEXT step (behind the first half of
     // them) instead of behind all of its own step's: a wave issues in order, so `mfma, mfma, load, ds_read, scalar work` leaves
     // everything but the matrix instructions to the one window behind the second of them; with the refill in the middle both windows
     // are used.  The slot refilled is the previous step's (its own step's B registers are still to be read), so the ring holds R - 1
     // steps ahead.
-    constexpr bool MID = CFG_REFILL_MID && TAPS == 9 && NDIL == 5 && P >= 2 && !(FLAGS & (F_S2PAIR | F_BNLOAD | F_EPI_PIPE)) && !ATX3;
+    constexpr bool MID = CFG_REFILL_MID && TAPS == 9 && NDIL == 5 && P >= 2 && !(FLAGS & (F_S2PAIR | F_BNLOAD | F_EPI_PIPE));
     constexpr int RB = MID ? 1 : 0;   // steps by which the refill lags
-    constexpr int RA = !ATX3 ? R : (R % 3 == 0 ? R : D);             // ring depth of the A operands (ATX3: whole row groups)
-    static_assert(!ATX3 || (TXN == 3 && D % RA == 0 && RA % 3 == 0 && !(FLAGS & (F_S2PAIR | F_S2_FLIP | F_EPI_PIPE))), "A_TX3 is for the branch kernels");
+    constexpr int RA = R;   // (ring depth of the A operands)
     static_assert(D % R == 0 && (R == D || !(FLAGS & (F_S2PAIR | F_BNLOAD | F_EPI_PIPE))), "the ring divides the chunk");
     constexpr int CPD = RGN / G;              // chunks per dilation
     constexpr int NCHUNK = NDIL * CPD;
@@ -631,34 +618,6 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
                 bl[g][p][2] = __builtin_bit_cast(float, e2);
             }
         };
-        // ATX3: the three horizontal taps of row group g of chunk c, one 12-byte read
-        typedef float f32x3a __attribute__((ext_vector_type(3), aligned(4)));
-        auto fetch_a3 = [&](int c, int g) {
-            const int di = c / CPD;
-            int ty0, sidx;
-            decode_rg(c - di * CPD, g, ty0, sidx);
-            const int row0 = ((di * 3 + ty0) * CINP + sidx * KL) * NROW;
-            float v0, v1, v2;
-            if (FLAGS & F_X_NOLDS) {
-                v0 = __builtin_bit_cast(float, row0 + lbase);
-                v1 = v0;
-                v2 = v0;
-            } else if (AGL) {
-                const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(rsrc_w, lbase * 12, row0 * 12, 0);
-                const unsigned e0 = v[0], e1 = v[1], e2 = v[2];
-                v0 = __builtin_bit_cast(float, e0);
-                v1 = __builtin_bit_cast(float, e1);
-                v2 = __builtin_bit_cast(float, e2);
-            } else {
-                const f32x3a v = *reinterpret_cast<const f32x3a *>(lds + (row0 + lbase) * 3);
-                v0 = v[0];
-                v1 = v[1];
-                v2 = v[2];
-            }
-            aq[(g * 3 + 0) % RA] = v0;
-            aq[(g * 3 + 1) % RA] = v1;
-            aq[(g * 3 + 2) % RA] = v2;
-        };
         auto fetch_a = [&](int c, int g, int tx, bool fl) {
             const int di = c / CPD;
             int ty0, sidx;
@@ -789,13 +748,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int tx = 0; tx < TXN; ++tx) {
-                    if (ATX3) {
-                        if (tx == 0 && g * 3 < RA)
-                            fetch_a3(c_first, g);
-                    } else if (g * TXN + tx < R - RB)
+                for (int tx = 0; tx < TXN; ++tx)
+                    if (g * TXN + tx < R - RB)
                         fetch_a(c_first, g, tx, flip);
-                }
         }
 
         if (BNL) {   // the task's first row group is transformed here, in one piece (once per ~150 k cycles)
@@ -945,9 +900,6 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
         }
 #endif
 
-#if CFG_UNROLL_CHUNKS
-#pragma unroll
-#endif
         for (int c = 0; c < NCHUNK; ++c) {
             if (NDIL > 1 && c % CPD == 0 && prio_mode == 0) {
                 // The two waves of a SIMD run the same program; arbitration prefers the older one, which
@@ -984,16 +936,14 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
                 const int v = u + R - RB;
                 if (v < D && (R < D || MID)) {
                     fetch_b(rsrc, sbase, c, v / TXN, v % TXN, flip);
-                    if (!ATX3)
-                        fetch_a(c, v / TXN, v % TXN, flip);
+                    fetch_a(c, v / TXN, v % TXN, flip);
                 } else {
                     const int gn = (v - D) / TXN, txn = (v - D) % TXN;
                     if (!S2P)
                         fetch_b(rs, sb, nx, gn, txn, fl);
                     else if (txn == 2)
                         fetch_pair(rs, sb, nx, gn, fl);
-                    if (!ATX3)
-                        fetch_a(nx, gn, txn, fl);
+                    fetch_a(nx, gn, txn, fl);
                 }
             };
             if (!SKIP || chunk_live(y, c)) {
@@ -1068,12 +1018,6 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
                     // the slot just consumed is refilled with the step R later: of this chunk, or of the next one
                     if (!MID)
                         refill(u);
-                    if (ATX3 && tx == 2) {   // the row group just consumed makes room for the one RA / 3 groups later
-                        if (g + RA / 3 < G)
-                            fetch_a3(c, g + RA / 3);
-                        else
-                            fetch_a3(nx, g + RA / 3 - G);
-                    }
                     // pin the ring order: left alone, hipcc sinks the refill loads to the end of the
                     // chunk, which shrinks the prefetch distance from D steps to a few
                     __builtin_amdgcn_sched_barrier(0);

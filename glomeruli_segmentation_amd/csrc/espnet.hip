@@ -180,17 +180,13 @@ static bool fold_bn(WeightTable &t, const std::string &bn, const std::string &ac
     return true;
 }
 
-// conv weight [cout][cin][k][k] -> LDS image rows [tap][cin_padded][nrow] of dilation slot `slot`; tx3 (conv_a_tx3: the branch
-// kernels): [tap row][cin_padded][nrow][tap column], a lane's three horizontal taps side by side
-static void pack_conv(const float *w, int cout, int cin, int k, float *dst, int slot, int taps, int cinp, int nrow, bool tx3 = false)
+// conv weight [cout][cin][k][k] -> LDS image rows [tap][cin_padded][nrow] of dilation slot `slot`
+static void pack_conv(const float *w, int cout, int cin, int k, float *dst, int slot, int taps, int cinp, int nrow)
 {
     for (int tap = 0; tap < taps; ++tap)
         for (int ci = 0; ci < cin; ++ci)
-            for (int co = 0; co < cout; ++co) {
-                const size_t at = tx3 ? ((((size_t)slot * 3 + tap / 3) * cinp + ci) * nrow + co) * 3 + tap % 3
-                                      : (((size_t)slot * taps + tap) * cinp + ci) * nrow + co;
-                dst[at] = w[((size_t)co * cin + ci) * k * k + tap];
-            }
+            for (int co = 0; co < cout; ++co)
+                dst[(((size_t)slot * taps + tap) * cinp + ci) * nrow + co] = w[((size_t)co * cin + ci) * k * k + tap];
 }
 
 // `next` names the block whose c1 (1x1 reduce of THIS block's output, Model.py:193) is computed in this block's epilogue
@@ -233,7 +229,7 @@ static bool pack_block(WeightTable &t, BlobBuilder &bb, const std::string &pre, 
         const float *w = t.get(pre + dn[di] + ".conv.weight", {co, n, 3, 3});
         if (!t.ok)
             return false;
-        pack_conv(w, co, n, 3, bb.data.data() + pc.br, di, 9, rcinp, n1, conv_a_tx3(9, 5));
+        pack_conv(w, co, n, 3, bb.data.data() + pc.br, di, 9, rcinp, n1);
     }
     if (pc.fused_next) {
         // table[di][r][lane]: the A operand of the k-step "accumulator register r of slot di": lane = (k-group, c1 output
