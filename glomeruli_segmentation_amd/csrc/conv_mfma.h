@@ -604,6 +604,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
                     float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + p * MT * STRIDE * 4, soff, IAUX));
         };
         auto fetch_pair = [&](const __amdgpu_buffer_rsrc_t &rs, int sb, int c, int g, bool fl) {
+            if ((FLAGS & F_X_NOLOAD) && staged)   // (timing only, as in fetch_b)
+                return;
             int ty0, sidx;
             decode_rg(c, g, ty0, sidx);
             const int ty = S2FLIP && fl ? TYN - 1 - ty0 : ty0;

@@ -192,8 +192,11 @@ constexpr int EPIPE_L2_ESP = (CFG_L2_EPI_PIPE & 1) ? F_EPI_PIPE : 0, EPIPE_L2_DO
 #ifndef POL_L3_C1
 #define POL_L3_C1 0
 #endif
+#ifndef CFG_L2C1S_XFLAGS
+#define CFG_L2C1S_XFLAGS 0   // -DGS_DIAG: F_X_NOLOAD on the level-2 stride-2 reduce = that launch without its 319 MB re-read of output0_cat
+#endif
 #ifndef POL_L2_C1S
-#define POL_L2_C1S 0
+#define POL_L2_C1S CFG_L2C1S_XFLAGS
 #endif
 #ifndef POL_L3_C1S
 #define POL_L3_C1S F_IN_NT   // 0.179 -> 0.165 ms; the same flag on the other inputs lost (decoder conv 0.19 -> 0.41: it lives on L2 row reuse)
