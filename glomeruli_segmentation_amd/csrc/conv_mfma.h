@@ -699,6 +699,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
             // round trip), every piece in flight at once; a register-staged copy loop took 9 us of a
             // 183 us launch here
             const int pieces = (a.wfloats - LDS_SRC0 + 255) / 256;
+            if ((FLAGS & F_X_STAMP2) && lane == 0)   // (diagnostic: the ramp in three pieces -- start -> here -> DMA issued -> staged)
+                a.stamp[wg * STAMP2_SLOTS + STAMP2_SLOTS - 2] = __builtin_amdgcn_s_memrealtime();
             // every workgroup starts at a different piece, so that the 256 CUs do not ask one L2 channel for the same
             // lines at the same moment (level-3 ESP launch 0.1888 -> 0.1866 ms, measured three times)
             const int rot = (int)((blockIdx.x * (unsigned)CFG_STAGE_ROT) % (unsigned)(pieces > 0 ? pieces : 1));
@@ -719,6 +721,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES >= 8 ? conv_min_waves(MT, TA
             // of the operand ring, and the epilogue's first residual use with another (round 6; tools/explore: the assembly of
             // both builds).  Same registers, same bits; measured the same speed at a 39-step ring (profiles/r06_ab_waitfix.txt), but
             // the ring and residual experiments of rounds 1-5 were all measured UNDER those forced drains.
+            if ((FLAGS & F_X_STAMP2) && lane == 0)
+                a.stamp[wg * STAMP2_SLOTS + STAMP2_SLOTS - 1] = __builtin_amdgcn_s_memrealtime();
 #if defined(CFG_X_BARRIER_COND)
             if (pieces > 0)
 #endif
