@@ -277,26 +277,27 @@ constexpr ConvImage conv_image(int CINP, int TAPS, int NDIL, int NOUT1, int NOUT
 #define CFG_RES_RING_DIV 1   // round 6: with the 13-step operand ring (CFG_L3_RING) a whole slot's residual fits (196 registers): requested at
                              // the top of its dilation (CFG_RES_TOP), no refill inside the epilogue
 #endif
-// Wave priority inside a branch kernel's epilogue (0 = leave the task's priority): the epilogue is a serial stretch in which this
-// wave feeds the matrix pipe next to nothing; at a priority above both task priorities it is through sooner.
+// ---- round-6 switches of the branch kernels' epilogue and k-step; each measured interleaved on one box with the same bits
+// (profiles/README.md, "Round 6", section 3); the defaults are what ships
+#ifndef CFG_RES_TOP
+#define CFG_RES_TOP 1       // a slot's residual requested at the top of its own dilation: level-2 ESP launch 0.1975 -> 0.194 ms (r06_ab_combo.txt)
+#endif
+#ifndef CFG_EPI_PRIO
+#define CFG_EPI_PRIO 0      // wave priority inside the epilogue (2 or 3 = above both task priorities): level-3 ESP -2 % alone, +0.5 % beside the
+                            // 13-step ring (r06_ab_epiprio.txt, r06_ab_combo.txt): off
+#endif
+#ifndef CFG_EPI_SPLIT
+#define CFG_EPI_SPLIT 0     // the fused 1x1's matrix instructions in one piece behind the slot's arithmetic: 0.1850 -> 0.1878 ms (r06_ab_sp2.txt): off
+#endif
+#ifndef CFG_EPI_PRELOAD
+#define CFG_EPI_PRELOAD 0   // 16x16x4 forms: a slot's BN constants all read up front: ESP unchanged, down-sampler 0.182 -> 0.196 (r06_ab_epi_preload.txt): off
+#endif
+#ifndef CFG_REFILL_MID
+#define CFG_REFILL_MID 0    // ring refill between the matrix instructions of the next step: level-3 ESP 0.1805 -> 0.1788, step +-0.3 % (r06_ab_refill_mid.txt): off
+#endif
 #ifndef CFG_X_EPI
 #define CFG_X_EPI 0   // GS_DIAG timing experiments on the epilogue's memory instructions (results wrong): 1 no residual loads, 2 no result
                       // stores, 4 residual loads of the even registers only, 8 result stores of the even registers only
-#endif
-#ifndef CFG_REFILL_MID
-#define CFG_REFILL_MID 0
-#endif
-#ifndef CFG_EPI_PRELOAD
-#define CFG_EPI_PRELOAD 0
-#endif
-#ifndef CFG_EPI_SPLIT
-#define CFG_EPI_SPLIT 0
-#endif
-#ifndef CFG_RES_TOP
-#define CFG_RES_TOP 1   // round 6: level-2 ESP launch 0.1975 -> 0.194 ms (profiles/r06_ab_combo.txt)
-#endif
-#ifndef CFG_EPI_PRIO
-#define CFG_EPI_PRIO 0
 #endif
 #ifndef CFG_STAGE_ROT
 #define CFG_STAGE_ROT 17   // 0 = every workgroup stages the weight image in the same order
